@@ -1,0 +1,226 @@
+/*
+ * vs_abi.h — C ABI of the MI355X vector-scan library (libvs_amd.so).
+ *
+ * This is the drop-in boundary for the filtered nearest-neighbour scan of the
+ * reference engine. The reference has no FFI of its own; the narrowest seam is
+ *   trait Context::vector_reader / embedder_category_id   src/search/context.rs:59-60
+ * consumed only by
+ *   VectorSort::fill_buffer                               src/search/ranking/vector_sort.rs:50-82
+ * which calls arroy 0.2.0 `Reader<Angular>::nns_by_vector(rtxn, target, limit,
+ * None, Some(&candidates))` (vector_sort.rs:73-77). Every entry point below
+ * names the reference call it replaces.
+ *
+ * Conventions
+ *  - every function returns an int32_t status (VS_OK == 0); nothing throws or
+ *    aborts across the boundary;
+ *  - the caller owns all host buffers it passes in; the library owns all device
+ *    memory and the opaque handles;
+ *  - document ids are the engine's internal `DocumentId = u32` (src/lib.rs:79);
+ *  - results are ordered ascending by (distance, docid), at most `k` of them,
+ *    exactly as arroy returns them from nns_by_vector;
+ *  - `vs_search*` are thread-safe and re-entrant on a sealed store; upload /
+ *    remove / seal need external exclusion (the engine has one LMDB writer);
+ *  - a search sees the state of the last `vs_store_seal` (RoTxn snapshot rule).
+ *
+ * There is no CPU fallback: without a usable HIP device `vs_init` fails with
+ * VS_E_DEVICE and no other entry point can be reached.
+ */
+#ifndef VS_ABI_H
+#define VS_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vs_ctx vs_ctx;     /* one per process and GPU */
+typedef struct vs_store vs_store; /* one arroy "index" = (embedder_id << 8) | k */
+
+/* Status codes. Mapping onto the reference's errors (src/error.rs:257-274):
+ *   VS_E_DIM_MISMATCH -> arroy::Error::InvalidVecDimension -> UserError::InvalidVectorDimensions
+ *   VS_E_NO_STORE     -> arroy::Error::MissingMetadata (loop terminator, vector_sort.rs:60-63)
+ *   everything else   -> InternalError::ArroyError */
+enum {
+    VS_OK = 0,
+    VS_E_INVALID_ARG = 1,
+    VS_E_DIM_MISMATCH = 2,
+    VS_E_NO_STORE = 3,
+    VS_E_DEVICE = 4,
+    VS_E_NOT_SEALED = 5,
+    VS_E_OOM = 6,
+    VS_E_CAPACITY = 7,
+    VS_E_FORMAT = 8
+};
+
+/* Element type of a store's rows in HBM. */
+enum { VS_F32 = 0, VS_BF16 = 1, VS_BIN1 = 2 };
+/* Distance. VS_ANGULAR is arroy::distances::Angular (src/index.rs:155), the only
+ * metric of the reference; VS_HAMMING exists for binary-quantised stores. */
+enum { VS_ANGULAR = 0, VS_HAMMING = 1 };
+
+/* Sentinel key that pads device-side key lists (see vs_search_device). */
+#define VS_KEY_NONE 0xFFFFFFFFFFFFFFFFull
+/* Largest `k` any search accepts. */
+#define VS_MAX_K 1024u
+
+/* ---- context ------------------------------------------------------------ */
+
+/* Binds the calling process to GPU `device_ordinal`. Replaces nothing in the
+ * reference (arroy needs no set-up); corresponds to opening the LMDB env. */
+int32_t vs_init(int32_t device_ordinal, vs_ctx** out);
+int32_t vs_shutdown(vs_ctx* ctx);
+
+/* Copies the calling thread's last error message (NUL terminated) into buf. */
+int32_t vs_last_error(vs_ctx* ctx, char* buf, size_t cap);
+/* After VS_E_DIM_MISMATCH: the two fields of arroy::Error::InvalidVecDimension
+ * {expected, received} (src/error.rs:262-264). */
+int32_t vs_last_dim_mismatch(vs_ctx* ctx, uint32_t* expected, uint32_t* received);
+
+/* Scan schedule knobs, for measurement only (no reference counterpart; results
+ * do not depend on them). map: 0 = slots dealt round-robin over the waves,
+ * 1 = 64-slot mask words dealt round-robin; blocks: grid size, 0 = default;
+ * nt: non-zero = non-temporal row loads. Also read once from the environment
+ * (VS_SCAN_MAP, VS_SCAN_BLOCKS, VS_SCAN_NT) by vs_init. */
+int32_t vs_set_scan_tuning(vs_ctx* ctx, int32_t map, int32_t blocks, int32_t nt);
+
+/* ---- stores ------------------------------------------------------------- */
+
+/* Creates the store `store_index` covering docids [docid_base, docid_base +
+ * capacity). Replaces arroy::Writer::new(db, index, dimensions)
+ * (src/update/index_documents/typed_chunk.rs:601-606). docid_base must be a
+ * multiple of 64. */
+int32_t vs_store_create(vs_ctx* ctx, uint16_t store_index, uint32_t dim, int32_t dtype,
+                        int32_t metric, uint32_t docid_base, uint64_t capacity, vs_store** out);
+
+/* Looks a store up by index. Replaces Context::vector_reader(index) =
+ * arroy::Reader::open (src/search/context.rs:188-190): a store that does not
+ * exist or was never sealed yields VS_E_NO_STORE, as Reader::open yields
+ * MissingMetadata for a store that was never built. */
+int32_t vs_store_open(vs_ctx* ctx, uint16_t store_index, vs_store** out);
+
+/* Adds or overwrites `n` items. `rows` is host memory, row-major f32 [n][dim];
+ * the library converts to the store's element type (bf16: round to nearest
+ * even; bin1: bit = (x > 0), bit i of a row in word i/64 at position i%64).
+ * Replaces arroy::Writer::add_item (typed_chunk.rs:650,691). */
+int32_t vs_store_upload(vs_store* s, const uint32_t* docids, const float* rows, uint64_t n);
+
+/* Adds `n` items with consecutive docids first_docid.. from DEVICE memory
+ * already in the store's native element type and row layout
+ * (vs_store_row_bytes per row, densely packed). */
+int32_t vs_store_upload_device(vs_store* s, uint32_t first_docid, const void* device_rows,
+                               uint64_t n, void* hip_stream);
+
+/* Replaces arroy::Writer::del_item (typed_chunk.rs:618,668,701). Unknown ids are ignored. */
+int32_t vs_store_remove(vs_store* s, const uint32_t* docids, uint64_t n);
+
+/* Makes every upload/remove since the previous seal visible to searches and
+ * precomputes the per-row norms (arroy stores ‖v‖ in each leaf header at
+ * add_item). Replaces arroy::Writer::build (src/update/index_documents/mod.rs:562). */
+int32_t vs_store_seal(vs_store* s);
+
+int32_t vs_store_destroy(vs_store* s);
+
+int32_t vs_store_len(vs_store* s, uint64_t* n_items);      /* arroy Reader::n_items */
+int32_t vs_store_dim(vs_store* s, uint32_t* dim);          /* arroy Reader::dimensions */
+int32_t vs_store_row_bytes(vs_store* s, uint64_t* bytes);  /* bytes of one row in HBM */
+/* arroy Writer::contains_item (typed_chunk.rs:673) */
+int32_t vs_store_contains(vs_store* s, uint32_t docid, int32_t* out);
+/* arroy Writer::item_vector (typed_chunk.rs:702): copies the row back as f32 [dim]
+ * (bf16 widened; bin1 as 0.0 / 1.0). VS_E_INVALID_ARG if the item is absent. */
+int32_t vs_store_item_vector(vs_store* s, uint32_t docid, float* out);
+
+/* ---- search, host buffers ------------------------------------------------ */
+
+/* Replaces reader.nns_by_vector(txn, target, limit, None, Some(candidates))
+ * (vector_sort.rs:73-77) in its exhaustive regime: the `k` nearest items among
+ * candidates ∩ items, ascending by (distance, docid).
+ *   mask_words: dense candidate bitmask over docids, bit (d & 63) of word d >> 6;
+ *               NULL means "every item" (the None case of arroy's API);
+ *               docids >= 64 * n_mask_words are not candidates.
+ *   out_ids / out_dist: room for k entries; *out_n <= k entries are written.
+ * k == 0 returns VS_OK with *out_n = 0 (arroy: count == 0 -> empty). */
+int32_t vs_search(vs_store* s, const float* query, uint32_t dim, uint32_t k,
+                  const uint64_t* mask_words, uint64_t n_mask_words, uint32_t* out_ids,
+                  float* out_dist, uint32_t* out_n);
+
+/* Same, the candidates given as a serialised RoaringBitmap — the bytes
+ * RoaringBitmap::serialize_into writes (src/heed_codec/roaring_bitmap/
+ * roaring_bitmap_codec.rs:29-33). Expanded to the dense mask on the device. */
+int32_t vs_search_roaring(vs_store* s, const float* query, uint32_t dim, uint32_t k,
+                          const uint8_t* roaring_bytes, size_t len, uint32_t* out_ids,
+                          float* out_dist, uint32_t* out_n);
+
+/* `n_q` queries against one shared candidate mask. out_ids / out_dist hold
+ * n_q * k entries (query i at offset i * k), out_n holds n_q counts. No
+ * reference counterpart (the reference searches one vector per request). */
+int32_t vs_search_batch(vs_store* s, const float* queries, uint32_t n_q, uint32_t dim,
+                        uint32_t k, const uint64_t* mask_words, uint64_t n_mask_words,
+                        uint32_t* out_ids, float* out_dist, uint32_t* out_n);
+
+/* ---- search, device buffers (asynchronous; multi-GPU and benchmark path) -- */
+
+/* Bytes of device workspace vs_search_device needs for this store and k. */
+int32_t vs_search_workspace_bytes(vs_store* s, uint32_t k, uint64_t* bytes);
+
+/* Enqueues one query on `hip_stream` and returns immediately.
+ *   d_query:      `dim` f32 (or dim/64 u64 words for VS_BIN1 stores) in device memory
+ *   d_mask_words: candidate words ALIGNED TO THE STORE: word j covers docids
+ *                 docid_base + 64 j .. ; capacity/64 words; NULL = every item
+ *   d_workspace:  vs_search_workspace_bytes bytes, private to this call until
+ *                 the stream has passed it
+ *   d_out_keys:   k u64 keys, ascending; key = (orderable(distance) << 32) |
+ *                 docid, padded with VS_KEY_NONE. This is the shard-local
+ *                 top-k a multi-GPU caller all-gathers. */
+int32_t vs_search_device(vs_store* s, const void* d_query, uint32_t dim, uint32_t k,
+                         const uint64_t* d_mask_words, void* d_workspace, uint64_t* d_out_keys,
+                         void* hip_stream);
+
+/* Merges `n_lists` ascending key lists of `k` entries each (list i at
+ * d_keys + i * k; e.g. the all-gathered shard results) into the global top-k
+ * and decodes it: d_out_ids[k], d_out_dist[k], *d_out_n. `metric` selects how a
+ * key's distance field is decoded (VS_ANGULAR: f32; VS_HAMMING: integer as f32). */
+int32_t vs_merge_topk_device(vs_ctx* ctx, const uint64_t* d_keys, uint32_t n_lists, uint32_t k,
+                             int32_t metric, uint32_t* d_out_ids, float* d_out_dist,
+                             uint32_t* d_out_n, void* hip_stream);
+
+/* `n_queries` such merges in one launch (one batch of queries after ONE
+ * all-gather): list i of query q starts at d_keys + q * query_stride + i *
+ * list_stride (in keys); outputs of query q at d_out_ids + q * k, d_out_dist +
+ * q * k, d_out_n + q. For the layout [rank][query][k] an all-gather of
+ * [query][k] produces: list_stride = n_queries * k, query_stride = k. */
+int32_t vs_merge_topk_batch_device(vs_ctx* ctx, const uint64_t* d_keys, uint32_t n_lists,
+                                   uint64_t list_stride, uint32_t n_queries, uint64_t query_stride,
+                                   uint32_t k, int32_t metric, uint32_t* d_out_ids,
+                                   float* d_out_dist, uint32_t* d_out_n, void* hip_stream);
+
+/* ---- candidate bitmaps ---------------------------------------------------- */
+
+/* Host-side expansion of a serialised RoaringBitmap into a dense mask of
+ * n_words words (docids beyond are dropped); *cardinality = bits set. Accepts
+ * both cookies of the portable format (with and without run containers). */
+int32_t vs_roaring_to_mask(const uint8_t* bytes, size_t len, uint64_t* words, uint64_t n_words,
+                           uint64_t* cardinality);
+
+/* Serialises a dense mask as the portable RoaringBitmap format without run
+ * containers (what roaring-rs writes). Call with out == NULL to get the size. */
+int32_t vs_mask_to_roaring(const uint64_t* words, uint64_t n_words, uint8_t* out, size_t cap,
+                           size_t* len);
+
+/* CboRoaringBitmapCodec::deserialize_from (src/heed_codec/roaring_bitmap/
+ * cbo_roaring_bitmap_codec.rs:44-58): <= 7 native-endian u32 when len <= 28,
+ * otherwise a serialised RoaringBitmap. */
+int32_t vs_cbo_roaring_to_mask(const uint8_t* bytes, size_t len, uint64_t* words,
+                               uint64_t n_words, uint64_t* cardinality);
+/* CboRoaringBitmapCodec::serialize_into (cbo_roaring_bitmap_codec.rs:30-42). */
+int32_t vs_mask_to_cbo_roaring(const uint64_t* words, uint64_t n_words, uint8_t* out, size_t cap,
+                               size_t* len);
+/* BoRoaringBitmapCodec (bo_roaring_bitmap_codec.rs:13-31): raw native-endian u32 list. */
+int32_t vs_bo_roaring_to_mask(const uint8_t* bytes, size_t len, uint64_t* words,
+                              uint64_t n_words, uint64_t* cardinality);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VS_ABI_H */

@@ -1,0 +1,121 @@
+// Device-side helpers shared by the scan kernels: wave-wide reductions on DPP,
+// the 64-bit (distance, docid) sort key, and the per-wave sorted top-k list
+// that lives in LDS. gfx950 only: a wavefront is 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr uint64_t KEY_NONE = 0xFFFFFFFFFFFFFFFFull;
+
+// ---- cross-lane ------------------------------------------------------------
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float v) {
+    // lanes whose row is not in ROW_MASK, or whose source lane is invalid, read 0
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+
+// Sum of `v` over the 64 lanes, returned wave-uniform. Fixed summation tree:
+// pairs, quads, 8, 16 inside each row of 16 lanes, then rows 0+1 and 2+3, then
+// the two halves; the total is read from lane 63.
+__device__ __forceinline__ float wave_sum_f32(float v) {
+    v += dpp_f32<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141, 0xF>(v);  // row_half_mirror
+    v += dpp_f32<0x140, 0xF>(v);  // row_mirror
+    v += dpp_f32<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
+    v += dpp_f32<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+    v += dpp_u32<0xB1, 0xF>(v);
+    v += dpp_u32<0x4E, 0xF>(v);
+    v += dpp_u32<0x141, 0xF>(v);
+    v += dpp_u32<0x140, 0xF>(v);
+    v += dpp_u32<0x142, 0xA>(v);
+    v += dpp_u32<0x143, 0xC>(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ uint32_t uniform_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+    const uint32_t lo = uniform_u32((uint32_t)v), hi = uniform_u32((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Stops the compiler from moving LDS accesses of one wave across this point.
+// The hardware returns one wave's LDS operations in issue order, so a wave that
+// stores and then loads through this fence reads what its own lanes stored.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- sort key ----------------------------------------------------------------
+
+// Monotone map f32 -> u32 for the total order OrderedFloat defines: -inf < ...
+// < -0 == +0 < ... < +inf < NaN (every NaN equal). arroy orders neighbours by
+// (OrderedFloat(distance), item id).
+__device__ __forceinline__ uint32_t f32_orderable(float d) {
+    if (d != d) return 0xFFC00000u;
+    d += 0.0f;  // -0.0 -> +0.0
+    const uint32_t u = __float_as_uint(d);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float f32_from_orderable(uint32_t o) {
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
+}
+__device__ __forceinline__ uint64_t make_key(uint32_t ordered_distance, uint32_t docid) {
+    return ((uint64_t)ordered_distance << 32) | docid;
+}
+
+// ---- per-wave sorted list in LDS ---------------------------------------------
+
+// `list` holds `k` keys ascending (KEY_NONE = empty slot) and belongs to ONE
+// wave. Inserts the wave-uniform `key`, which the caller has checked to be
+// smaller than list[k-1]; the last entry drops out. Returns the new list[k-1].
+__device__ __forceinline__ uint64_t list_insert(volatile uint64_t* list, int k, uint64_t key,
+                                                int lane) {
+    int pos = 0;
+    for (int base = 0; base < k; base += 64) {
+        const int i = base + lane;
+        const bool lt = (i < k) && (list[i] < key);
+        pos += __popcll(__ballot(lt));
+    }
+    // shift [pos, k-1) up by one, top chunk first so nothing is overwritten
+    // before it has been read
+    for (int base = ((k - 1) >> 6) << 6; base >= 0 && base + 63 > pos; base -= 64) {
+        const int i = base + lane;
+        const bool mv = (i < k) && (i > pos);
+        uint64_t v = 0;
+        if (mv) v = list[i - 1];
+        wave_lds_fence();
+        if (mv) list[i] = v;
+        wave_lds_fence();
+    }
+    if (lane == 0) list[pos] = key;
+    wave_lds_fence();
+    return uniform_u64(list[k - 1]);
+}
+
+}  // namespace vs

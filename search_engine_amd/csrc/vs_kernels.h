@@ -1,0 +1,82 @@
+// Host-callable launchers of the HIP kernels (implemented in vs_kernels.hip).
+// Everything here enqueues work on the given stream and returns; nothing
+// allocates or synchronises.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vs {
+
+// Geometry of a row slab in HBM. Rows are stored row-major, one row per
+// docid slot (slot = docid - docid_base), each row `row_vecs` 16-byte vectors
+// long and zero padded; `n_slots` is a multiple of 64.
+struct SlabView {
+    const void* rows;         // n_slots * row_vecs * 16 bytes
+    const float* norms;       // n_slots (angular stores), ‖row‖₂
+    const uint64_t* present;  // n_slots / 64 words, bit set = slot holds an item
+    uint64_t n_slots;
+    uint32_t row_vecs;    // 16-byte vectors per row
+    uint32_t dim;         // logical dimension (elements, or bits for bin1)
+    uint32_t docid_base;  // multiple of 64
+    int32_t dtype;        // VS_F32 / VS_BF16 / VS_BIN1
+};
+
+// Scan tuning knobs (0 = library default); exposed so the benchmark can A/B
+// schedules in one process.
+struct ScanTuning {
+    int32_t map;     // 0: rows interleaved over waves, 1: 64-row words per wave
+    int32_t blocks;  // grid size
+    int32_t nt;      // 1: non-temporal row loads
+};
+
+uint32_t scan_grid_blocks(const SlabView& s, const ScanTuning& t);
+// device bytes of the partial-list buffer one scan of this slab writes
+uint64_t scan_partial_bytes(const SlabView& s, uint32_t k, const ScanTuning& t);
+
+// Angular scan of one query (f32 or bf16 rows): writes the per-workgroup top-k
+// lists to `partial` and then the merged ascending top-k keys to `out_keys[k]`
+// (nullable) and, decoded, to out_ids / out_dist / out_n (nullable as a group).
+// `cand` (nullable) is aligned with `present`.
+hipError_t launch_scan_angular(const SlabView& s, const float* d_query, const uint64_t* cand,
+                               uint32_t k, uint64_t* partial, uint64_t* out_keys,
+                               uint32_t* out_ids, float* out_dist, uint32_t* out_n,
+                               const ScanTuning& t, hipStream_t stream);
+
+// ‖row‖₂ for slots [slot0, slot0 + n) of an angular slab, same summation order
+// as the scan uses for ⟨row, query⟩.
+hipError_t launch_norms(const SlabView& s, float* norms, uint64_t slot0, uint64_t n,
+                        hipStream_t stream);
+
+// Scatter `n` staged f32 rows [n][dim] into the slab at slot docids[i] -
+// docid_base, converting to the slab's element type.
+hipError_t launch_ingest_f32(const SlabView& s, void* rows_out, const float* staged,
+                             const uint32_t* docids, uint64_t n, hipStream_t stream);
+
+// Merge `n_lists` ascending key lists (entry r of list l at keys[l * list_stride
+// + r * rank_stride]) into the ascending global top-k `out_keys[k]`; when
+// out_ids is non-null also decode it into (ids, distances, count).
+hipError_t launch_merge(const uint64_t* keys, uint32_t n_lists, uint64_t list_stride,
+                        uint64_t rank_stride, uint32_t k, int32_t metric, uint64_t* out_keys,
+                        uint32_t* out_ids, float* out_dist, uint32_t* out_n, hipStream_t stream);
+
+// The same for `n_queries` independent merges in one launch: query q reads its
+// lists at keys + q * query_stride and writes out_*[q * k ..], out_n[q].
+hipError_t launch_merge_batch(const uint64_t* keys, uint32_t n_lists, uint64_t list_stride,
+                              uint64_t rank_stride, uint32_t n_queries, uint64_t query_stride,
+                              uint32_t k, int32_t metric, uint64_t* out_keys, uint32_t* out_ids,
+                              float* out_dist, uint32_t* out_n, hipStream_t stream);
+
+// Expand a serialised RoaringBitmap already in device memory into the dense
+// mask `words[n_words]` covering docids [docid_base, docid_base + 64 n_words).
+// `desc` is the host-parsed container table copied to the device.
+struct RoaringContainerDesc {
+    uint32_t key;       // high 16 bits of the docids
+    uint32_t kind;      // 0 array, 1 bitmap, 2 run
+    uint32_t count;     // array: values, run: runs, bitmap: unused
+    uint32_t offset;    // byte offset of the payload inside the serialised blob
+};
+hipError_t launch_roaring_expand(const uint8_t* d_bytes, const RoaringContainerDesc* d_desc,
+                                 uint32_t n_containers, uint32_t docid_base, uint64_t* words,
+                                 uint64_t n_words, hipStream_t stream);
+
+}  // namespace vs

@@ -1,0 +1,550 @@
+// HIP kernels of the filtered vector scan (gfx950 / CDNA4, wave64).
+//
+// The scan replaces the exhaustive regime of arroy 0.2.0
+// `Reader<Angular>::nns_by_vector` as the reference calls it from
+// VectorSort::fill_buffer (src/search/ranking/vector_sort.rs:73-77): every item
+// of the store that is in the candidate bitmap gets its Angular distance to the
+// query, and the `k` smallest by (distance, docid) come back.
+//
+// Shape of the work: one query against N rows is a matrix-vector product that
+// reads every passing row exactly once, so it is bound by HBM bandwidth. The
+// kernel therefore
+//   * keeps the query in registers (each lane owns the slice of the query that
+//     matches the 16-byte vectors it loads from every row),
+//   * gives one wave one row at a time: a row is read by full-wave 1 KiB
+//     loads straight into registers (no LDS staging: nothing is reused),
+//   * tests the candidate bit BEFORE a row is loaded, so rows that the filter
+//     rejects cost no HBM traffic at all,
+//   * reduces the 64 per-lane partial sums on DPP (no LDS), and
+//   * keeps a sorted top-k list per wave in LDS that is only touched when a
+//     row beats the wave's current k-th best (rare after the first few rows).
+#include "vs_kernels.h"
+
+#include "../../include/vs_abi.h"
+#include "vs_device.h"
+
+namespace vs {
+
+constexpr int WAVES = 4;               // waves per workgroup
+constexpr int SB = 4;                  // 64-candidate mask batches per queue refill
+constexpr int QCAP = SB * 64 + 16;     // row queue entries per wave
+constexpr uint32_t MAX_BLOCKS = 1024;  // 4 workgroups on each of the 256 CUs
+
+struct ScanArgs {
+    const u32x4* rows;
+    const float* norms;
+    const uint64_t* present;
+    const uint64_t* cand;
+    const float* query;
+    uint64_t* partial;  // [k][gridDim.x], rank-major
+    uint64_t n_slots;
+    uint32_t row_vecs;
+    uint32_t dim;
+    uint32_t docid_base;
+    uint32_t k;
+};
+
+__device__ __forceinline__ uint32_t lanes_below(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+}
+
+// i-th candidate slot of wave `w` out of `W`.
+//   MAP 0: slots are dealt round-robin over the waves (wave w owns w, w+W, ...):
+//          at any moment the whole chip reads one contiguous window of the slab.
+//   MAP 1: 64-slot words are dealt round-robin (wave w owns words w, w+W, ...):
+//          one mask word per 64 candidates, each wave streams 64 adjacent rows.
+template <int MAP>
+__device__ __forceinline__ uint64_t slot_of(uint64_t i, uint32_t w, uint32_t W) {
+    if (MAP == 0) return i * W + w;
+    return ((((i >> 6) * W) + w) << 6) | (i & 63);
+}
+template <int MAP>
+__device__ __forceinline__ uint64_t slots_of_wave(uint64_t n_slots, uint32_t w, uint32_t W) {
+    if (MAP == 0) return w < n_slots ? (n_slots - w + W - 1) / W : 0;
+    const uint64_t n_words = n_slots >> 6;
+    return w < n_words ? ((n_words - w + W - 1) / W) << 6 : 0;
+}
+
+// Elements of one 16-byte row vector: 4 f32 or 8 bf16.
+template <int ELEM>
+struct Epv {
+    static constexpr int value = ELEM == VS_F32 ? 4 : 8;
+};
+
+// acc += <one 16-byte row vector, the matching query slice>, fixed order.
+template <int ELEM>
+__device__ __forceinline__ float dot_vec(u32x4 x, const float* q, float acc) {
+    if (ELEM == VS_F32) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_fmaf(__uint_as_float(x[j]), q[j], acc);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc = __builtin_fmaf(__uint_as_float(x[j] << 16), q[2 * j], acc);
+            acc = __builtin_fmaf(__uint_as_float(x[j] & 0xFFFF0000u), q[2 * j + 1], acc);
+        }
+    }
+    return acc;
+}
+// acc += <vector, vector> for the norm.
+template <int ELEM>
+__device__ __forceinline__ float self_dot_vec(u32x4 x, float acc) {
+    if (ELEM == VS_F32) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = __uint_as_float(x[j]);
+            acc = __builtin_fmaf(v, v, acc);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lo = __uint_as_float(x[j] << 16), hi = __uint_as_float(x[j] & 0xFFFF0000u);
+            acc = __builtin_fmaf(lo, lo, acc);
+            acc = __builtin_fmaf(hi, hi, acc);
+        }
+    }
+    return acc;
+}
+
+template <bool NT>
+__device__ __forceinline__ u32x4 load_vec(const u32x4* p) {
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+
+// arroy 0.2.0 Angular::built_distance: cos = <p,q> / (‖p‖‖q‖); d = (1 - cos) / 2,
+// and 0 when ‖p‖‖q‖ == 0.
+__device__ __forceinline__ float angular_distance(float pq, float pn, float qn) {
+    const float pnqn = pn * qn;
+    if (pnqn != 0.0f) {
+        const float c = pq / pnqn;
+        return (1.0f - c) / 2.0f;
+    }
+    return 0.0f;
+}
+
+template <int ELEM, int NCH, int U, int MAP, bool NT>
+__global__ __launch_bounds__(WAVES * 64) void scan_angular_kernel(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int EPV = Epv<ELEM>::value;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wib = uniform_u32(threadIdx.x >> 6);
+    const uint32_t W = gridDim.x * WAVES;
+    const uint32_t w = blockIdx.x * WAVES + wib;
+    const int k = (int)a.k;
+
+    volatile uint64_t* list = reinterpret_cast<volatile uint64_t*>(smem) + (size_t)wib * k;
+    volatile uint32_t* queue =
+        reinterpret_cast<volatile uint32_t*>(smem + (size_t)WAVES * k * 8) + (size_t)wib * QCAP;
+    for (int i = lane; i < k; i += 64) list[i] = KEY_NONE;
+    uint64_t tau = KEY_NONE;
+
+    // this lane's slice of the query, and ‖q‖ summed in the row order
+    float q[NCH][EPV];
+    float qq = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+            const uint32_t e = (uint32_t)(c * 64 + lane) * EPV + j;
+            q[c][j] = e < a.dim ? a.query[e] : 0.0f;
+            qq = __builtin_fmaf(q[c][j], q[c][j], qq);
+        }
+    }
+    const float qn = sqrtf(wave_sum_f32(qq));
+    wave_lds_fence();
+
+    // Scores rows queue[head .. head+U); the first `nvalid` of them count.
+    auto score_rows = [&](uint32_t head, uint32_t nvalid) {
+        uint32_t slot[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t at = head + ((uint32_t)u < nvalid ? (uint32_t)u : nvalid - 1);
+            slot[u] = uniform_u32(queue[at]);
+        }
+        u32x4 x[U][NCH];
+        float pn[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const u32x4* rp = a.rows + (uint64_t)slot[u] * a.row_vecs;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const uint32_t idx = (uint32_t)(c * 64 + lane);
+                if (c < NCH - 1 || idx < a.row_vecs) {
+                    x[u][c] = load_vec<NT>(rp + idx);
+                } else {
+                    x[u][c] = u32x4{0u, 0u, 0u, 0u};
+                }
+            }
+            pn[u] = a.norms[slot[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) acc = dot_vec<ELEM>(x[u][c], q[c], acc);
+            const float pq = wave_sum_f32(acc);
+            const float d = angular_distance(pq, pn[u], qn);
+            const uint64_t key = make_key(uniform_u32(f32_orderable(d)), a.docid_base + slot[u]);
+            if ((uint32_t)u < nvalid && key < tau) tau = list_insert(list, k, key, lane);
+        }
+    };
+
+    const uint64_t n_i = slots_of_wave<MAP>(a.n_slots, w, W);
+    uint32_t qcount = 0;
+    for (uint64_t i0 = 0; i0 < n_i; i0 += SB * 64) {
+        // refill the queue with the slots of the next SB * 64 candidates that pass
+#pragma unroll
+        for (int b = 0; b < SB; ++b) {
+            const uint64_t i = i0 + (uint64_t)(b * 64 + lane);
+            bool pass = false;
+            uint32_t slot = 0;
+            if (i < n_i) {
+                const uint64_t s = slot_of<MAP>(i, w, W);
+                uint64_t wd = a.present[s >> 6];
+                if (a.cand) wd &= a.cand[s >> 6];
+                pass = (wd >> (s & 63)) & 1;
+                slot = (uint32_t)s;
+            }
+            const uint64_t m = __ballot(pass);
+            if (pass) queue[qcount + lanes_below(m)] = slot;
+            qcount += (uint32_t)__popcll(m);
+        }
+        wave_lds_fence();
+        uint32_t head = 0;
+        while (qcount - head >= (uint32_t)U) {
+            score_rows(head, U);
+            head += U;
+        }
+        // keep the (< U) leftovers for the next round
+        const uint32_t rem = qcount - head;
+        uint32_t v = 0;
+        if ((uint32_t)lane < rem) v = queue[head + lane];
+        wave_lds_fence();
+        if ((uint32_t)lane < rem) queue[lane] = v;
+        wave_lds_fence();
+        qcount = rem;
+    }
+    if (qcount) score_rows(0, qcount);
+
+    // workgroup merge: wave 0 absorbs the other waves' lists
+    __syncthreads();
+    if (wib == 0) {
+        for (int v = 1; v < WAVES; ++v) {
+            volatile uint64_t* other = reinterpret_cast<volatile uint64_t*>(smem) + (size_t)v * k;
+            for (int j = 0; j < k; ++j) {
+                const uint64_t key = uniform_u64(other[j]);
+                if (key >= tau) break;
+                tau = list_insert(list, k, key, lane);
+            }
+        }
+        for (int i = lane; i < k; i += 64)
+            a.partial[(uint64_t)i * gridDim.x + blockIdx.x] = list[i];
+    }
+}
+
+// ---- merge of sorted key lists ------------------------------------------------
+
+// One workgroup per query: blockIdx.x selects the query's key lists
+// (keys + blockIdx.x * query_stride) and its slice of every output.
+__global__ __launch_bounds__(256) void merge_kernel(const uint64_t* keys, uint32_t n_lists,
+                                                    uint64_t list_stride, uint64_t rank_stride,
+                                                    uint64_t query_stride, uint32_t k_,
+                                                    int32_t metric, uint64_t* out_keys,
+                                                    uint32_t* out_ids, float* out_dist,
+                                                    uint32_t* out_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    keys += (uint64_t)blockIdx.x * query_stride;
+    if (out_keys) out_keys += (uint64_t)blockIdx.x * k_;
+    if (out_ids) {
+        out_ids += (uint64_t)blockIdx.x * k_;
+        out_dist += (uint64_t)blockIdx.x * k_;
+    }
+    if (out_n) out_n += blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wv = uniform_u32(threadIdx.x >> 6);
+    const int k = (int)k_;
+    volatile uint64_t* list = reinterpret_cast<volatile uint64_t*>(smem) + (size_t)wv * k;
+    for (int i = lane; i < k; i += 64) list[i] = KEY_NONE;
+    wave_lds_fence();
+    uint64_t tau = KEY_NONE;
+
+    // Every input list is ascending, so once no list of this wave has its
+    // rank-r entry below tau, no later rank can have one either.
+    for (int r = 0; r < k; ++r) {
+        bool any = false;
+        for (uint32_t base = 0; base < n_lists; base += 1024) {
+            uint64_t key[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t l = base + (uint32_t)b * 256 + wv * 64 + lane;
+                key[b] = l < n_lists ? keys[(uint64_t)l * list_stride + (uint64_t)r * rank_stride]
+                                     : KEY_NONE;
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                uint64_t m = __ballot(key[b] < tau);
+                while (m) {
+                    const int src = __builtin_ctzll(m);
+                    tau = list_insert(list, k, readlane_u64(key[b], src), lane);
+                    any = true;
+                    m &= m - 1;
+                    m &= __ballot(key[b] < tau);
+                }
+            }
+        }
+        if (!any) break;
+    }
+    __syncthreads();
+    if (wv == 0) {
+        for (int v = 1; v < 4; ++v) {
+            volatile uint64_t* other = reinterpret_cast<volatile uint64_t*>(smem) + (size_t)v * k;
+            for (int j = 0; j < k; ++j) {
+                const uint64_t key = uniform_u64(other[j]);
+                if (key >= tau) break;
+                tau = list_insert(list, k, key, lane);
+            }
+        }
+        uint32_t n = 0;
+        for (int base = 0; base < k; base += 64) {
+            const int i = base + lane;
+            const uint64_t key = i < k ? list[i] : KEY_NONE;
+            if (i < k) {
+                if (out_keys) out_keys[i] = key;
+                if (out_ids) {
+                    const uint32_t hi = (uint32_t)(key >> 32);
+                    out_ids[i] = (uint32_t)key;
+                    out_dist[i] = key == KEY_NONE ? 0.0f
+                                  : metric == VS_HAMMING ? (float)hi
+                                                         : f32_from_orderable(hi);
+                }
+            }
+            n += (uint32_t)__popcll(__ballot(key != KEY_NONE));
+        }
+        if (out_n && lane == 0) *out_n = n;
+    }
+}
+
+// ---- norms ---------------------------------------------------------------------
+
+template <int ELEM>
+__global__ __launch_bounds__(256) void norms_kernel(const u32x4* rows, uint32_t row_vecs,
+                                                    float* norms, uint64_t slot0, uint64_t n) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t W = (uint64_t)gridDim.x * 4;
+    for (uint64_t i = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += W) {
+        const u32x4* rp = rows + (slot0 + i) * row_vecs;
+        float acc = 0.0f;
+        // same per-lane order as the scan: chunk by chunk, element by element
+        for (uint32_t idx = lane; idx < row_vecs; idx += 64) acc = self_dot_vec<ELEM>(rp[idx], acc);
+        const float s = wave_sum_f32(acc);
+        if (lane == 0) norms[slot0 + i] = sqrtf(s);
+    }
+}
+
+// ---- ingest ----------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t f32_to_bf16_rne(float f) {
+    uint32_t u = __float_as_uint(f);
+    if (f != f) return 0x7FC0u;
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+
+// one wave per staged row
+__global__ __launch_bounds__(256) void ingest_f32_kernel(unsigned char* rows_out, uint32_t row_vecs,
+                                                         uint32_t dim, uint32_t docid_base,
+                                                         int32_t dtype, const float* staged,
+                                                         const uint32_t* docids, uint64_t n) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t W = (uint64_t)gridDim.x * 4;
+    for (uint64_t i = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += W) {
+        const float* src = staged + i * dim;
+        unsigned char* dst = rows_out + (uint64_t)(docids[i] - docid_base) * row_vecs * 16;
+        if (dtype == VS_F32) {
+            float* o = reinterpret_cast<float*>(dst);
+            for (uint32_t e = lane; e < row_vecs * 4; e += 64) o[e] = e < dim ? src[e] : 0.0f;
+        } else if (dtype == VS_BF16) {
+            uint16_t* o = reinterpret_cast<uint16_t*>(dst);
+            for (uint32_t e = lane; e < row_vecs * 8; e += 64)
+                o[e] = e < dim ? (uint16_t)f32_to_bf16_rne(src[e]) : (uint16_t)0;
+        } else {
+            uint64_t* o = reinterpret_cast<uint64_t*>(dst);
+            for (uint32_t e0 = 0; e0 < row_vecs * 128; e0 += 64) {
+                const uint32_t e = e0 + lane;
+                const uint64_t bits = __ballot(e < dim && src[e] > 0.0f);
+                if (lane == 0) o[e0 >> 6] = bits;
+            }
+        }
+    }
+}
+
+// ---- roaring -> dense mask ----------------------------------------------------------
+
+// One workgroup per container; `words` was zeroed by the caller.
+__global__ __launch_bounds__(256) void roaring_expand_kernel(const uint8_t* bytes,
+                                                             const RoaringContainerDesc* desc,
+                                                             uint32_t docid_base, uint64_t* words,
+                                                             uint64_t n_words) {
+    const RoaringContainerDesc d = desc[blockIdx.x];
+    const int64_t word0 = ((int64_t)d.key << 10) - (int64_t)(docid_base >> 6);
+    const uint8_t* p = bytes + d.offset;
+    auto in_range = [&](int64_t wi) { return wi >= 0 && (uint64_t)wi < n_words; };
+    if (d.kind == 1) {  // 1024 little-endian u64 words
+        for (uint32_t i = threadIdx.x; i < 1024; i += blockDim.x) {
+            uint64_t v = 0;
+            for (int b = 0; b < 8; ++b) v |= (uint64_t)p[i * 8 + b] << (8 * b);
+            if (v && in_range(word0 + i)) atomicOr((unsigned long long*)&words[word0 + i], v);
+        }
+    } else if (d.kind == 0) {  // sorted u16 values
+        for (uint32_t i = threadIdx.x; i < d.count; i += blockDim.x) {
+            const uint32_t v = (uint32_t)p[2 * i] | ((uint32_t)p[2 * i + 1] << 8);
+            const int64_t wi = word0 + (v >> 6);
+            if (in_range(wi)) atomicOr((unsigned long long*)&words[wi], 1ull << (v & 63));
+        }
+    } else {  // runs: (start, length - 1) u16 pairs
+        for (uint32_t i = threadIdx.x; i < d.count; i += blockDim.x) {
+            const uint32_t s = (uint32_t)p[4 * i] | ((uint32_t)p[4 * i + 1] << 8);
+            const uint32_t e = s + ((uint32_t)p[4 * i + 2] | ((uint32_t)p[4 * i + 3] << 8));
+            for (uint32_t wq = s >> 6; wq <= (e >> 6) && wq < 1024; ++wq) {
+                const uint32_t lo = wq == (s >> 6) ? (s & 63) : 0;
+                const uint32_t hi = wq == (e >> 6) ? (e & 63) : 63;
+                const uint64_t m = (hi == 63 ? ~0ull : ((1ull << (hi + 1)) - 1)) & ~((1ull << lo) - 1);
+                if (in_range(word0 + wq)) atomicOr((unsigned long long*)&words[word0 + wq], m);
+            }
+        }
+    }
+}
+
+// ---- launchers ------------------------------------------------------------------------
+
+uint32_t scan_grid_blocks(const SlabView& s, const ScanTuning& t) {
+    if (t.blocks > 0) return (uint32_t)t.blocks;
+    const uint64_t want = (s.n_slots + 1023) / 1024;  // >= 256 slots per wave
+    return (uint32_t)(want < 1 ? 1 : want > MAX_BLOCKS ? MAX_BLOCKS : want);
+}
+
+uint64_t scan_partial_bytes(const SlabView& s, uint32_t k, const ScanTuning& t) {
+    return (uint64_t)scan_grid_blocks(s, t) * k * sizeof(uint64_t);
+}
+
+template <int ELEM, int NCH, int U>
+static hipError_t launch_scan_t(const ScanArgs& a, uint32_t blocks, size_t lds, const ScanTuning& t,
+                                hipStream_t stream) {
+    const dim3 grid(blocks), block(WAVES * 64);
+    if (t.map == 0) {
+        if (t.nt)
+            hipLaunchKernelGGL((scan_angular_kernel<ELEM, NCH, U, 0, true>), grid, block, lds, stream, a);
+        else
+            hipLaunchKernelGGL((scan_angular_kernel<ELEM, NCH, U, 0, false>), grid, block, lds, stream, a);
+    } else {
+        if (t.nt)
+            hipLaunchKernelGGL((scan_angular_kernel<ELEM, NCH, U, 1, true>), grid, block, lds, stream, a);
+        else
+            hipLaunchKernelGGL((scan_angular_kernel<ELEM, NCH, U, 1, false>), grid, block, lds, stream, a);
+    }
+    return hipGetLastError();
+}
+
+template <int ELEM>
+static hipError_t launch_scan_e(const ScanArgs& a, uint32_t blocks, size_t lds, const ScanTuning& t,
+                                hipStream_t stream) {
+    const uint32_t nch = (a.row_vecs + 63) / 64;
+    if (nch <= 1) return launch_scan_t<ELEM, 1, 8>(a, blocks, lds, t, stream);
+    if (nch <= 2) return launch_scan_t<ELEM, 2, 8>(a, blocks, lds, t, stream);
+    if (nch <= 3) return launch_scan_t<ELEM, 3, 4>(a, blocks, lds, t, stream);
+    if (nch <= 4) return launch_scan_t<ELEM, 4, 4>(a, blocks, lds, t, stream);
+    if (nch <= 6) return launch_scan_t<ELEM, 6, 2>(a, blocks, lds, t, stream);
+    if (nch <= 8) return launch_scan_t<ELEM, 8, 2>(a, blocks, lds, t, stream);
+    if (nch <= 12) return launch_scan_t<ELEM, 12, 1>(a, blocks, lds, t, stream);
+    if (nch <= 16) return launch_scan_t<ELEM, 16, 1>(a, blocks, lds, t, stream);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_scan_angular(const SlabView& s, const float* d_query, const uint64_t* cand,
+                               uint32_t k, uint64_t* partial, uint64_t* out_keys,
+                               uint32_t* out_ids, float* out_dist, uint32_t* out_n,
+                               const ScanTuning& t, hipStream_t stream) {
+    if (k == 0 || k > VS_MAX_K || (s.n_slots & 63) || s.n_slots == 0) return hipErrorInvalidValue;
+    ScanArgs a;
+    a.rows = reinterpret_cast<const u32x4*>(s.rows);
+    a.norms = s.norms;
+    a.present = s.present;
+    a.cand = cand;
+    a.query = d_query;
+    a.partial = partial;
+    a.n_slots = s.n_slots;
+    a.row_vecs = s.row_vecs;
+    a.dim = s.dim;
+    a.docid_base = s.docid_base;
+    a.k = k;
+    const uint32_t blocks = scan_grid_blocks(s, t);
+    const size_t lds = (size_t)WAVES * k * 8 + (size_t)WAVES * QCAP * 4;
+    hipError_t e;
+    if (s.dtype == VS_F32)
+        e = launch_scan_e<VS_F32>(a, blocks, lds, t, stream);
+    else if (s.dtype == VS_BF16)
+        e = launch_scan_e<VS_BF16>(a, blocks, lds, t, stream);
+    else
+        return hipErrorInvalidValue;
+    if (e != hipSuccess) return e;
+    return launch_merge(partial, blocks, 1, blocks, k, VS_ANGULAR, out_keys, out_ids, out_dist,
+                        out_n, stream);
+}
+
+hipError_t launch_merge(const uint64_t* keys, uint32_t n_lists, uint64_t list_stride,
+                        uint64_t rank_stride, uint32_t k, int32_t metric, uint64_t* out_keys,
+                        uint32_t* out_ids, float* out_dist, uint32_t* out_n, hipStream_t stream) {
+    return launch_merge_batch(keys, n_lists, list_stride, rank_stride, 1, 0, k, metric, out_keys,
+                              out_ids, out_dist, out_n, stream);
+}
+
+hipError_t launch_merge_batch(const uint64_t* keys, uint32_t n_lists, uint64_t list_stride,
+                              uint64_t rank_stride, uint32_t n_queries, uint64_t query_stride,
+                              uint32_t k, int32_t metric, uint64_t* out_keys, uint32_t* out_ids,
+                              float* out_dist, uint32_t* out_n, hipStream_t stream) {
+    if (k == 0 || k > VS_MAX_K || n_lists == 0 || n_queries == 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(merge_kernel, dim3(n_queries), dim3(256), (size_t)4 * k * 8, stream, keys,
+                       n_lists, list_stride, rank_stride, query_stride, k, metric, out_keys, out_ids,
+                       out_dist, out_n);
+    return hipGetLastError();
+}
+
+hipError_t launch_norms(const SlabView& s, float* norms, uint64_t slot0, uint64_t n,
+                        hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const uint64_t want = (n + 3) / 4;
+    const uint32_t blocks = (uint32_t)(want > 4096 ? 4096 : want);
+    const u32x4* rows = reinterpret_cast<const u32x4*>(s.rows);
+    if (s.dtype == VS_F32)
+        hipLaunchKernelGGL(norms_kernel<VS_F32>, dim3(blocks), dim3(256), 0, stream, rows, s.row_vecs,
+                           norms, slot0, n);
+    else if (s.dtype == VS_BF16)
+        hipLaunchKernelGGL(norms_kernel<VS_BF16>, dim3(blocks), dim3(256), 0, stream, rows,
+                           s.row_vecs, norms, slot0, n);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_ingest_f32(const SlabView& s, void* rows_out, const float* staged,
+                             const uint32_t* docids, uint64_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const uint64_t want = (n + 3) / 4;
+    const uint32_t blocks = (uint32_t)(want > 4096 ? 4096 : want);
+    hipLaunchKernelGGL(ingest_f32_kernel, dim3(blocks), dim3(256), 0, stream,
+                       reinterpret_cast<unsigned char*>(rows_out), s.row_vecs, s.dim, s.docid_base,
+                       s.dtype, staged, docids, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_roaring_expand(const uint8_t* d_bytes, const RoaringContainerDesc* d_desc,
+                                 uint32_t n_containers, uint32_t docid_base, uint64_t* words,
+                                 uint64_t n_words, hipStream_t stream) {
+    if (n_containers == 0) return hipSuccess;
+    hipLaunchKernelGGL(roaring_expand_kernel, dim3(n_containers), dim3(256), 0, stream, d_bytes,
+                       d_desc, docid_base, words, n_words);
+    return hipGetLastError();
+}
+
+}  // namespace vs

@@ -1,0 +1,693 @@
+// Host side of libvs_amd.so: contexts, stores (row slabs in HBM), the workspace
+// pool that makes searches re-entrant, and the C-ABI entry points declared in
+// include/vs_abi.h. No computation happens here; every distance is produced by
+// the kernels in vs_kernels.hip, and there is no CPU fallback.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/vs_abi.h"
+#include "vs_kernels.h"
+#include "vs_roaring.h"
+
+namespace {
+
+thread_local std::string g_err;
+thread_local uint32_t g_dim_expected = 0, g_dim_received = 0;
+
+int32_t fail(int32_t code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        const hipError_t e_ = (expr);                                                      \
+        if (e_ != hipSuccess)                                                              \
+            return fail(e_ == hipErrorOutOfMemory ? VS_E_OOM : VS_E_DEVICE, "%s failed: %s", \
+                        #expr, hipGetErrorString(e_));                                     \
+    } while (0)
+
+constexpr uint32_t MAX_DIM_VECS = 16 * 64;  // row vectors the scan kernels are built for
+constexpr size_t STAGE_BYTES = 32u << 20;
+
+// Everything one in-flight host-buffer search needs; handed out by the pool so
+// that concurrent vs_search calls never share a stream or a buffer.
+struct Workspace {
+    hipStream_t stream = nullptr;
+    float* d_query = nullptr;
+    uint64_t* d_mask = nullptr;
+    size_t mask_words = 0;
+    uint64_t* d_partial = nullptr;
+    size_t partial_bytes = 0;
+    uint64_t* d_keys = nullptr;  // VS_MAX_K keys, ids, distances and the count, one allocation
+    uint32_t* d_ids = nullptr;
+    float* d_dist = nullptr;
+    uint32_t* d_n = nullptr;
+    uint8_t* d_blob = nullptr;
+    size_t blob_bytes = 0;
+    unsigned char* h_pinned = nullptr;  // query, then results
+    size_t pinned_bytes = 0;
+
+    ~Workspace() {
+        if (d_query) (void)hipFree(d_query);
+        if (d_mask) (void)hipFree(d_mask);
+        if (d_partial) (void)hipFree(d_partial);
+        if (d_keys) (void)hipFree(d_keys);
+        if (d_blob) (void)hipFree(d_blob);
+        if (h_pinned) (void)hipHostFree(h_pinned);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+constexpr size_t QUERY_BYTES = (size_t)MAX_DIM_VECS * 16 * 2;  // bf16 rows: 8 f32 per vector
+constexpr size_t RESULT_BYTES = (size_t)VS_MAX_K * 8 + 64;
+
+}  // namespace
+
+struct vs_ctx {
+    int device = 0;
+    std::mutex mu;  // stores map, pool, staging
+    std::map<uint16_t, vs_store*> stores;
+    std::vector<std::unique_ptr<Workspace>> pool;
+    vs::ScanTuning tuning{0, 0, 0};
+    // upload staging (guarded by upload_mu)
+    std::mutex upload_mu;
+    unsigned char* h_stage = nullptr;
+    unsigned char* d_stage = nullptr;
+    hipStream_t upload_stream = nullptr;
+};
+
+struct vs_store {
+    vs_ctx* ctx = nullptr;
+    uint16_t index = 0;
+    uint32_t dim = 0;
+    int32_t dtype = VS_F32, metric = VS_ANGULAR;
+    uint32_t docid_base = 0;
+    uint64_t capacity = 0, n_slots = 0;
+    uint32_t row_vecs = 0;
+    void* d_rows = nullptr;
+    float* d_norms = nullptr;
+    uint64_t* d_present[2] = {nullptr, nullptr};  // searches read [active]; seal fills the other
+    std::atomic<int> active{0};
+    std::vector<uint64_t> h_present;  // writer's view, published by seal
+    uint64_t n_items = 0;             // of h_present
+    std::atomic<uint64_t> sealed_items{0};
+    uint64_t dirty_lo = 0, dirty_hi = 0;  // slot range uploaded since the last seal
+    bool dirty = false;
+    std::atomic<bool> sealed{false};
+
+    vs::SlabView view() const {
+        vs::SlabView v;
+        v.rows = d_rows;
+        v.norms = d_norms;
+        v.present = d_present[active.load(std::memory_order_acquire)];
+        v.n_slots = n_slots;
+        v.row_vecs = row_vecs;
+        v.dim = dim;
+        v.docid_base = docid_base;
+        v.dtype = dtype;
+        return v;
+    }
+    uint64_t row_bytes() const { return (uint64_t)row_vecs * 16; }
+};
+
+namespace {
+
+int32_t ws_acquire(vs_ctx* ctx, std::unique_ptr<Workspace>* out) {
+    {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        if (!ctx->pool.empty()) {
+            *out = std::move(ctx->pool.back());
+            ctx->pool.pop_back();
+            return VS_OK;
+        }
+    }
+    std::unique_ptr<Workspace> ws(new Workspace());
+    HIP_TRY(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc(&ws->d_query, QUERY_BYTES));
+    unsigned char* out_block = nullptr;
+    HIP_TRY(hipMalloc(&out_block, (size_t)VS_MAX_K * 16 + 64));
+    ws->d_keys = reinterpret_cast<uint64_t*>(out_block);
+    ws->d_ids = reinterpret_cast<uint32_t*>(out_block + (size_t)VS_MAX_K * 8);
+    ws->d_dist = reinterpret_cast<float*>(out_block + (size_t)VS_MAX_K * 12);
+    ws->d_n = reinterpret_cast<uint32_t*>(out_block + (size_t)VS_MAX_K * 16);
+    ws->pinned_bytes = QUERY_BYTES + RESULT_BYTES;
+    HIP_TRY(hipHostMalloc(&ws->h_pinned, ws->pinned_bytes, hipHostMallocDefault));
+    *out = std::move(ws);
+    return VS_OK;
+}
+
+void ws_release(vs_ctx* ctx, std::unique_ptr<Workspace> ws) {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    ctx->pool.push_back(std::move(ws));
+}
+
+template <typename T>
+int32_t grow(T** p, size_t* have, size_t want) {
+    if (*have >= want) return VS_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *have = 0;
+    HIP_TRY(hipMalloc(p, want));
+    *have = want;
+    return VS_OK;
+}
+
+uint32_t vecs_for(uint32_t dim, int32_t dtype) {
+    if (dtype == VS_F32) return (dim + 3) / 4;
+    if (dtype == VS_BF16) return (dim + 7) / 8;
+    return (dim + 127) / 128;
+}
+
+int32_t check_store(vs_store* s) {
+    if (!s) return fail(VS_E_INVALID_ARG, "null store handle");
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    return VS_OK;
+}
+
+// Common front half of the host-buffer searches: argument checks and the query upload.
+int32_t begin_search(vs_store* s, const float* query, uint32_t dim, uint32_t k, uint32_t* out_ids,
+                     float* out_dist, uint32_t* out_n) {
+    if (int32_t rc = check_store(s)) return rc;
+    if (!query || !out_n || (k && (!out_ids || !out_dist)))
+        return fail(VS_E_INVALID_ARG, "null query or output buffer");
+    if (!s->sealed.load()) return fail(VS_E_NOT_SEALED, "store %u was never sealed", s->index);
+    if (dim != s->dim) {
+        g_dim_expected = s->dim;
+        g_dim_received = dim;
+        return fail(VS_E_DIM_MISMATCH, "invalid vector dimensions: expected %u, received %u", s->dim,
+                    dim);
+    }
+    if (k > VS_MAX_K) return fail(VS_E_INVALID_ARG, "k = %u exceeds VS_MAX_K = %u", k, VS_MAX_K);
+    if (s->metric != VS_ANGULAR || s->dtype == VS_BIN1)
+        return fail(VS_E_INVALID_ARG, "store %u is not an angular f32/bf16 store", s->index);
+    return VS_OK;
+}
+
+// Runs one query whose candidate mask (aligned to the store, or null) is already
+// on the device, and copies the decoded result back.
+int32_t run_and_fetch(vs_store* s, Workspace* ws, const float* h_query, uint32_t k,
+                      const uint64_t* d_cand, uint32_t* out_ids, float* out_dist, uint32_t* out_n) {
+    const vs::SlabView v = s->view();
+    const vs::ScanTuning& t = s->ctx->tuning;
+    if (int32_t rc = grow(&ws->d_partial, &ws->partial_bytes, (size_t)vs::scan_partial_bytes(v, k, t)))
+        return rc;
+    float* hq = reinterpret_cast<float*>(ws->h_pinned);
+    memcpy(hq, h_query, (size_t)s->dim * 4);
+    HIP_TRY(hipMemcpyAsync(ws->d_query, hq, (size_t)s->dim * 4, hipMemcpyHostToDevice, ws->stream));
+    HIP_TRY(vs::launch_scan_angular(v, ws->d_query, d_cand, k, ws->d_partial, nullptr, ws->d_ids,
+                                    ws->d_dist, ws->d_n, t, ws->stream));
+    unsigned char* hr = ws->h_pinned + QUERY_BYTES;
+    // ids, distances and the count are contiguous on the device
+    HIP_TRY(hipMemcpyAsync(hr, ws->d_ids, (size_t)VS_MAX_K * 8 + 4, hipMemcpyDeviceToHost, ws->stream));
+    HIP_TRY(hipStreamSynchronize(ws->stream));
+    uint32_t n;
+    memcpy(&n, hr + (size_t)VS_MAX_K * 8, 4);
+    if (n > k) return fail(VS_E_DEVICE, "device returned %u results for k = %u", n, k);
+    memcpy(out_ids, hr, (size_t)n * 4);
+    memcpy(out_dist, hr + (size_t)VS_MAX_K * 4, (size_t)n * 4);
+    *out_n = n;
+    return VS_OK;
+}
+
+// Copies the caller's docid-indexed mask into ws->d_mask, aligned to the store.
+int32_t stage_dense_mask(vs_store* s, Workspace* ws, const uint64_t* mask_words,
+                         uint64_t n_mask_words) {
+    const uint64_t n_words = s->n_slots / 64;
+    if (int32_t rc = grow(&ws->d_mask, &ws->mask_words, (size_t)n_words * 8)) return rc;
+    const uint64_t w0 = s->docid_base / 64;
+    const uint64_t avail = n_mask_words > w0 ? n_mask_words - w0 : 0;
+    const uint64_t ncopy = avail < n_words ? avail : n_words;
+    if (ncopy)
+        HIP_TRY(hipMemcpyAsync(ws->d_mask, mask_words + w0, (size_t)ncopy * 8, hipMemcpyHostToDevice,
+                               ws->stream));
+    if (ncopy < n_words)
+        HIP_TRY(hipMemsetAsync(ws->d_mask + ncopy, 0, (size_t)(n_words - ncopy) * 8, ws->stream));
+    return VS_OK;
+}
+
+}  // namespace
+
+// ---- context -------------------------------------------------------------------
+
+extern "C" int32_t vs_init(int32_t device_ordinal, vs_ctx** out) {
+    if (!out) return fail(VS_E_INVALID_ARG, "null out pointer");
+    *out = nullptr;
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(VS_E_DEVICE, "no HIP device: %s (this library has no CPU path)",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device_ordinal < 0 || device_ordinal >= n)
+        return fail(VS_E_INVALID_ARG, "device %d out of range (%d devices)", device_ordinal, n);
+    HIP_TRY(hipSetDevice(device_ordinal));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(VS_E_DEVICE, "device %d is %s; the kernels are built for gfx950 only",
+                    device_ordinal, prop.gcnArchName);
+    std::unique_ptr<vs_ctx> ctx(new vs_ctx());
+    ctx->device = device_ordinal;
+    if (const char* v = getenv("VS_SCAN_MAP")) ctx->tuning.map = atoi(v);
+    if (const char* v = getenv("VS_SCAN_BLOCKS")) ctx->tuning.blocks = atoi(v);
+    if (const char* v = getenv("VS_SCAN_NT")) ctx->tuning.nt = atoi(v);
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
+    *out = ctx.release();
+    return VS_OK;
+}
+
+extern "C" int32_t vs_shutdown(vs_ctx* ctx) {
+    if (!ctx) return VS_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    std::vector<vs_store*> stores;
+    {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        for (auto& kv : ctx->stores) stores.push_back(kv.second);
+    }
+    for (vs_store* s : stores) vs_store_destroy(s);
+    ctx->pool.clear();
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+    if (ctx->upload_stream) (void)hipStreamDestroy(ctx->upload_stream);
+    delete ctx;
+    return VS_OK;
+}
+
+extern "C" int32_t vs_last_error(vs_ctx*, char* buf, size_t cap) {
+    if (!buf || !cap) return VS_E_INVALID_ARG;
+    snprintf(buf, cap, "%s", g_err.c_str());
+    return VS_OK;
+}
+
+extern "C" int32_t vs_last_dim_mismatch(vs_ctx*, uint32_t* expected, uint32_t* received) {
+    if (expected) *expected = g_dim_expected;
+    if (received) *received = g_dim_received;
+    return VS_OK;
+}
+
+extern "C" int32_t vs_set_scan_tuning(vs_ctx* ctx, int32_t map, int32_t blocks, int32_t nt) {
+    if (!ctx) return fail(VS_E_INVALID_ARG, "null context");
+    if (map < 0 || map > 1 || blocks < 0 || blocks > 65535)
+        return fail(VS_E_INVALID_ARG, "bad tuning values");
+    ctx->tuning = vs::ScanTuning{map, blocks, nt ? 1 : 0};
+    return VS_OK;
+}
+
+// ---- stores ------------------------------------------------------------------------
+
+extern "C" int32_t vs_store_create(vs_ctx* ctx, uint16_t store_index, uint32_t dim, int32_t dtype,
+                                   int32_t metric, uint32_t docid_base, uint64_t capacity,
+                                   vs_store** out) {
+    if (!ctx || !out) return fail(VS_E_INVALID_ARG, "null context or out pointer");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (dim == 0) return fail(VS_E_INVALID_ARG, "dimension 0");
+    if (dtype != VS_F32 && dtype != VS_BF16 && dtype != VS_BIN1)
+        return fail(VS_E_INVALID_ARG, "unknown element type %d", dtype);
+    if ((dtype == VS_BIN1) != (metric == VS_HAMMING))
+        return fail(VS_E_INVALID_ARG, "bin1 stores use VS_HAMMING, f32/bf16 stores VS_ANGULAR");
+    if (docid_base % 64) return fail(VS_E_INVALID_ARG, "docid_base must be a multiple of 64");
+    if (capacity == 0 || (uint64_t)docid_base + capacity > (1ull << 32))
+        return fail(VS_E_INVALID_ARG, "docid range [%u, %u + %llu) does not fit u32 docids", docid_base,
+                    docid_base, (unsigned long long)capacity);
+    const uint32_t row_vecs = vecs_for(dim, dtype);
+    if (row_vecs > MAX_DIM_VECS)
+        return fail(VS_E_INVALID_ARG, "dimension %u too large (row of %u bytes, limit %u)", dim,
+                    row_vecs * 16, MAX_DIM_VECS * 16);
+    {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        if (ctx->stores.count(store_index))
+            return fail(VS_E_INVALID_ARG, "store %u already exists", store_index);
+    }
+    std::unique_ptr<vs_store> s(new vs_store());
+    s->ctx = ctx;
+    s->index = store_index;
+    s->dim = dim;
+    s->dtype = dtype;
+    s->metric = metric;
+    s->docid_base = docid_base;
+    s->capacity = capacity;
+    s->n_slots = (capacity + 63) / 64 * 64;
+    s->row_vecs = row_vecs;
+    const size_t n_words = s->n_slots / 64;
+    HIP_TRY(hipMalloc(&s->d_rows, (size_t)s->n_slots * s->row_bytes()));
+    HIP_TRY(hipMalloc(&s->d_present[0], n_words * 8));
+    HIP_TRY(hipMalloc(&s->d_present[1], n_words * 8));
+    HIP_TRY(hipMemset(s->d_present[0], 0, n_words * 8));
+    HIP_TRY(hipMemset(s->d_present[1], 0, n_words * 8));
+    if (metric == VS_ANGULAR) {
+        HIP_TRY(hipMalloc(&s->d_norms, (size_t)s->n_slots * 4));
+        HIP_TRY(hipMemset(s->d_norms, 0, (size_t)s->n_slots * 4));
+    }
+    s->h_present.assign(n_words, 0);
+    {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        ctx->stores[store_index] = s.get();
+    }
+    *out = s.release();
+    return VS_OK;
+}
+
+extern "C" int32_t vs_store_open(vs_ctx* ctx, uint16_t store_index, vs_store** out) {
+    if (!ctx || !out) return fail(VS_E_INVALID_ARG, "null context or out pointer");
+    *out = nullptr;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    auto it = ctx->stores.find(store_index);
+    if (it == ctx->stores.end() || !it->second->sealed.load())
+        return fail(VS_E_NO_STORE, "missing metadata for store %u", store_index);
+    *out = it->second;
+    return VS_OK;
+}
+
+extern "C" int32_t vs_store_destroy(vs_store* s) {
+    if (!s) return VS_OK;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipDeviceSynchronize();
+    {
+        std::lock_guard<std::mutex> g(s->ctx->mu);
+        s->ctx->stores.erase(s->index);
+    }
+    if (s->d_rows) (void)hipFree(s->d_rows);
+    if (s->d_norms) (void)hipFree(s->d_norms);
+    if (s->d_present[0]) (void)hipFree(s->d_present[0]);
+    if (s->d_present[1]) (void)hipFree(s->d_present[1]);
+    delete s;
+    return VS_OK;
+}
+
+namespace {
+void mark_present(vs_store* s, uint64_t slot) {
+    uint64_t& w = s->h_present[slot >> 6];
+    const uint64_t bit = 1ull << (slot & 63);
+    if (!(w & bit)) {
+        w |= bit;
+        ++s->n_items;
+    }
+    if (!s->dirty) {
+        s->dirty = true;
+        s->dirty_lo = s->dirty_hi = slot;
+    } else {
+        if (slot < s->dirty_lo) s->dirty_lo = slot;
+        if (slot > s->dirty_hi) s->dirty_hi = slot;
+    }
+}
+}  // namespace
+
+extern "C" int32_t vs_store_upload(vs_store* s, const uint32_t* docids, const float* rows,
+                                   uint64_t n) {
+    if (int32_t rc = check_store(s)) return rc;
+    if (n == 0) return VS_OK;
+    if (!docids || !rows) return fail(VS_E_INVALID_ARG, "null docids or rows");
+    for (uint64_t i = 0; i < n; ++i)
+        if (docids[i] < s->docid_base || (uint64_t)docids[i] - s->docid_base >= s->capacity)
+            return fail(VS_E_CAPACITY, "docid %u outside the store's range [%u, %llu)", docids[i],
+                        s->docid_base, (unsigned long long)(s->docid_base + s->capacity));
+    vs_ctx* ctx = s->ctx;
+    std::lock_guard<std::mutex> g(ctx->upload_mu);
+    if (!ctx->h_stage) HIP_TRY(hipHostMalloc(&ctx->h_stage, STAGE_BYTES, hipHostMallocDefault));
+    if (!ctx->d_stage) HIP_TRY(hipMalloc(&ctx->d_stage, STAGE_BYTES));
+    const size_t per_row = (size_t)s->dim * 4 + 4;
+    const uint64_t chunk = STAGE_BYTES / per_row;
+    const vs::SlabView v = s->view();
+    for (uint64_t at = 0; at < n; at += chunk) {
+        const uint64_t m = n - at < chunk ? n - at : chunk;
+        const size_t row_b = (size_t)m * s->dim * 4;
+        memcpy(ctx->h_stage, rows + at * s->dim, row_b);
+        memcpy(ctx->h_stage + row_b, docids + at, (size_t)m * 4);
+        HIP_TRY(hipMemcpyAsync(ctx->d_stage, ctx->h_stage, row_b + (size_t)m * 4,
+                               hipMemcpyHostToDevice, ctx->upload_stream));
+        HIP_TRY(vs::launch_ingest_f32(v, s->d_rows, reinterpret_cast<const float*>(ctx->d_stage),
+                                      reinterpret_cast<const uint32_t*>(ctx->d_stage + row_b), m,
+                                      ctx->upload_stream));
+        HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
+    }
+    for (uint64_t i = 0; i < n; ++i) mark_present(s, docids[i] - s->docid_base);
+    return VS_OK;
+}
+
+extern "C" int32_t vs_store_upload_device(vs_store* s, uint32_t first_docid,
+                                          const void* device_rows, uint64_t n, void* hip_stream) {
+    if (int32_t rc = check_store(s)) return rc;
+    if (n == 0) return VS_OK;
+    if (!device_rows) return fail(VS_E_INVALID_ARG, "null device rows");
+    if (first_docid < s->docid_base || (uint64_t)first_docid - s->docid_base + n > s->capacity)
+        return fail(VS_E_CAPACITY, "docids [%u, %u + %llu) outside the store's range", first_docid,
+                    first_docid, (unsigned long long)n);
+    const uint64_t slot0 = first_docid - s->docid_base;
+    HIP_TRY(hipMemcpyAsync(static_cast<unsigned char*>(s->d_rows) + slot0 * s->row_bytes(),
+                           device_rows, (size_t)n * s->row_bytes(), hipMemcpyDeviceToDevice,
+                           static_cast<hipStream_t>(hip_stream)));
+    std::lock_guard<std::mutex> g(s->ctx->upload_mu);
+    for (uint64_t i = 0; i < n; ++i) mark_present(s, slot0 + i);
+    return VS_OK;
+}
+
+extern "C" int32_t vs_store_remove(vs_store* s, const uint32_t* docids, uint64_t n) {
+    if (int32_t rc = check_store(s)) return rc;
+    if (n && !docids) return fail(VS_E_INVALID_ARG, "null docids");
+    std::lock_guard<std::mutex> g(s->ctx->upload_mu);
+    for (uint64_t i = 0; i < n; ++i) {
+        if (docids[i] < s->docid_base || (uint64_t)docids[i] - s->docid_base >= s->capacity) continue;
+        const uint64_t slot = docids[i] - s->docid_base;
+        uint64_t& w = s->h_present[slot >> 6];
+        const uint64_t bit = 1ull << (slot & 63);
+        if (w & bit) {
+            w &= ~bit;
+            --s->n_items;
+        }
+    }
+    return VS_OK;
+}
+
+extern "C" int32_t vs_store_seal(vs_store* s) {
+    if (int32_t rc = check_store(s)) return rc;
+    vs_ctx* ctx = s->ctx;
+    std::lock_guard<std::mutex> g(ctx->upload_mu);
+    // uploads may have been enqueued on caller streams
+    HIP_TRY(hipDeviceSynchronize());
+    if (s->dirty && s->metric == VS_ANGULAR) {
+        const vs::SlabView v = s->view();
+        HIP_TRY(vs::launch_norms(v, s->d_norms, s->dirty_lo, s->dirty_hi - s->dirty_lo + 1,
+                                 ctx->upload_stream));
+    }
+    const int next = 1 - s->active.load();
+    HIP_TRY(hipMemcpyAsync(s->d_present[next], s->h_present.data(), s->h_present.size() * 8,
+                           hipMemcpyHostToDevice, ctx->upload_stream));
+    HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
+    s->active.store(next, std::memory_order_release);
+    s->sealed_items.store(s->n_items);
+    s->dirty = false;
+    s->sealed.store(true);
+    return VS_OK;
+}
+
+extern "C" int32_t vs_store_len(vs_store* s, uint64_t* n_items) {
+    if (!s || !n_items) return fail(VS_E_INVALID_ARG, "null argument");
+    *n_items = s->sealed_items.load();
+    return VS_OK;
+}
+
+extern "C" int32_t vs_store_dim(vs_store* s, uint32_t* dim) {
+    if (!s || !dim) return fail(VS_E_INVALID_ARG, "null argument");
+    *dim = s->dim;
+    return VS_OK;
+}
+
+extern "C" int32_t vs_store_row_bytes(vs_store* s, uint64_t* bytes) {
+    if (!s || !bytes) return fail(VS_E_INVALID_ARG, "null argument");
+    *bytes = s->row_bytes();
+    return VS_OK;
+}
+
+extern "C" int32_t vs_store_contains(vs_store* s, uint32_t docid, int32_t* out) {
+    if (!s || !out) return fail(VS_E_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> g(s->ctx->upload_mu);
+    *out = 0;
+    if (docid >= s->docid_base && (uint64_t)docid - s->docid_base < s->capacity) {
+        const uint64_t slot = docid - s->docid_base;
+        *out = (int32_t)((s->h_present[slot >> 6] >> (slot & 63)) & 1);
+    }
+    return VS_OK;
+}
+
+extern "C" int32_t vs_store_item_vector(vs_store* s, uint32_t docid, float* out) {
+    if (int32_t rc = check_store(s)) return rc;
+    if (!out) return fail(VS_E_INVALID_ARG, "null output");
+    int32_t has = 0;
+    vs_store_contains(s, docid, &has);
+    if (!has) return fail(VS_E_INVALID_ARG, "item %u is not in store %u", docid, s->index);
+    std::vector<unsigned char> row(s->row_bytes());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(row.data(),
+                      static_cast<unsigned char*>(s->d_rows) +
+                          (uint64_t)(docid - s->docid_base) * s->row_bytes(),
+                      row.size(), hipMemcpyDeviceToHost));
+    for (uint32_t e = 0; e < s->dim; ++e) {
+        if (s->dtype == VS_F32) {
+            memcpy(&out[e], row.data() + 4 * e, 4);
+        } else if (s->dtype == VS_BF16) {
+            uint16_t h;
+            memcpy(&h, row.data() + 2 * e, 2);
+            const uint32_t u = (uint32_t)h << 16;
+            memcpy(&out[e], &u, 4);
+        } else {
+            uint64_t w;
+            memcpy(&w, row.data() + 8 * (e / 64), 8);
+            out[e] = (float)((w >> (e % 64)) & 1);
+        }
+    }
+    return VS_OK;
+}
+
+// ---- search, host buffers ----------------------------------------------------------------
+
+extern "C" int32_t vs_search(vs_store* s, const float* query, uint32_t dim, uint32_t k,
+                             const uint64_t* mask_words, uint64_t n_mask_words, uint32_t* out_ids,
+                             float* out_dist, uint32_t* out_n) {
+    if (int32_t rc = begin_search(s, query, dim, k, out_ids, out_dist, out_n)) return rc;
+    *out_n = 0;
+    if (k == 0) return VS_OK;
+    std::unique_ptr<Workspace> ws;
+    if (int32_t rc = ws_acquire(s->ctx, &ws)) return rc;
+    int32_t rc = VS_OK;
+    const uint64_t* d_cand = nullptr;
+    if (mask_words) {
+        rc = stage_dense_mask(s, ws.get(), mask_words, n_mask_words);
+        d_cand = ws->d_mask;
+    }
+    if (rc == VS_OK) rc = run_and_fetch(s, ws.get(), query, k, d_cand, out_ids, out_dist, out_n);
+    ws_release(s->ctx, std::move(ws));
+    return rc;
+}
+
+extern "C" int32_t vs_search_roaring(vs_store* s, const float* query, uint32_t dim, uint32_t k,
+                                     const uint8_t* roaring_bytes, size_t len, uint32_t* out_ids,
+                                     float* out_dist, uint32_t* out_n) {
+    if (int32_t rc = begin_search(s, query, dim, k, out_ids, out_dist, out_n)) return rc;
+    *out_n = 0;
+    if (!roaring_bytes) return fail(VS_E_INVALID_ARG, "null roaring bytes");
+    std::vector<vs::RoaringContainerDesc> desc;
+    if (!vs::roaring_parse(roaring_bytes, len, &desc))
+        return fail(VS_E_FORMAT, "malformed serialised RoaringBitmap (%zu bytes)", len);
+    if (k == 0) return VS_OK;
+    std::unique_ptr<Workspace> ws;
+    if (int32_t rc = ws_acquire(s->ctx, &ws)) return rc;
+    auto body = [&]() -> int32_t {
+        const uint64_t n_words = s->n_slots / 64;
+        if (int32_t rc = grow(&ws->d_mask, &ws->mask_words, (size_t)n_words * 8)) return rc;
+        HIP_TRY(hipMemsetAsync(ws->d_mask, 0, (size_t)n_words * 8, ws->stream));
+        if (!desc.empty()) {
+            const size_t blob = (len + 15) / 16 * 16;
+            const size_t desc_b = desc.size() * sizeof(vs::RoaringContainerDesc);
+            if (int32_t rc = grow(&ws->d_blob, &ws->blob_bytes, blob + desc_b)) return rc;
+            HIP_TRY(hipMemcpyAsync(ws->d_blob, roaring_bytes, len, hipMemcpyHostToDevice, ws->stream));
+            HIP_TRY(hipMemcpyAsync(ws->d_blob + blob, desc.data(), desc_b, hipMemcpyHostToDevice,
+                                   ws->stream));
+            HIP_TRY(vs::launch_roaring_expand(
+                ws->d_blob, reinterpret_cast<const vs::RoaringContainerDesc*>(ws->d_blob + blob),
+                (uint32_t)desc.size(), s->docid_base, ws->d_mask, n_words, ws->stream));
+        }
+        return run_and_fetch(s, ws.get(), query, k, ws->d_mask, out_ids, out_dist, out_n);
+    };
+    const int32_t rc = body();
+    ws_release(s->ctx, std::move(ws));
+    return rc;
+}
+
+extern "C" int32_t vs_search_batch(vs_store* s, const float* queries, uint32_t n_q, uint32_t dim,
+                                   uint32_t k, const uint64_t* mask_words, uint64_t n_mask_words,
+                                   uint32_t* out_ids, float* out_dist, uint32_t* out_n) {
+    if (n_q == 0) return VS_OK;
+    if (int32_t rc = begin_search(s, queries, dim, k, out_ids, out_dist, out_n)) return rc;
+    for (uint32_t i = 0; i < n_q; ++i) out_n[i] = 0;
+    if (k == 0) return VS_OK;
+    std::unique_ptr<Workspace> ws;
+    if (int32_t rc = ws_acquire(s->ctx, &ws)) return rc;
+    int32_t rc = VS_OK;
+    const uint64_t* d_cand = nullptr;
+    if (mask_words) {
+        rc = stage_dense_mask(s, ws.get(), mask_words, n_mask_words);
+        d_cand = ws->d_mask;
+    }
+    for (uint32_t i = 0; i < n_q && rc == VS_OK; ++i)
+        rc = run_and_fetch(s, ws.get(), queries + (size_t)i * dim, k, d_cand, out_ids + (size_t)i * k,
+                           out_dist + (size_t)i * k, out_n + i);
+    ws_release(s->ctx, std::move(ws));
+    return rc;
+}
+
+// ---- search, device buffers ------------------------------------------------------------------
+
+extern "C" int32_t vs_search_workspace_bytes(vs_store* s, uint32_t k, uint64_t* bytes) {
+    if (!s || !bytes) return fail(VS_E_INVALID_ARG, "null argument");
+    if (k == 0 || k > VS_MAX_K) return fail(VS_E_INVALID_ARG, "k = %u out of range", k);
+    *bytes = vs::scan_partial_bytes(s->view(), k, s->ctx->tuning);
+    return VS_OK;
+}
+
+extern "C" int32_t vs_search_device(vs_store* s, const void* d_query, uint32_t dim, uint32_t k,
+                                    const uint64_t* d_mask_words, void* d_workspace,
+                                    uint64_t* d_out_keys, void* hip_stream) {
+    if (int32_t rc = check_store(s)) return rc;
+    if (!d_query || !d_workspace || !d_out_keys) return fail(VS_E_INVALID_ARG, "null device buffer");
+    if (!s->sealed.load()) return fail(VS_E_NOT_SEALED, "store %u was never sealed", s->index);
+    if (dim != s->dim) {
+        g_dim_expected = s->dim;
+        g_dim_received = dim;
+        return fail(VS_E_DIM_MISMATCH, "invalid vector dimensions: expected %u, received %u", s->dim,
+                    dim);
+    }
+    if (k == 0 || k > VS_MAX_K) return fail(VS_E_INVALID_ARG, "k = %u out of range", k);
+    if (s->metric != VS_ANGULAR || s->dtype == VS_BIN1)
+        return fail(VS_E_INVALID_ARG, "store %u is not an angular f32/bf16 store", s->index);
+    HIP_TRY(vs::launch_scan_angular(s->view(), static_cast<const float*>(d_query), d_mask_words, k,
+                                    static_cast<uint64_t*>(d_workspace), d_out_keys, nullptr, nullptr,
+                                    nullptr, s->ctx->tuning, static_cast<hipStream_t>(hip_stream)));
+    return VS_OK;
+}
+
+extern "C" int32_t vs_merge_topk_device(vs_ctx* ctx, const uint64_t* d_keys, uint32_t n_lists,
+                                        uint32_t k, int32_t metric, uint32_t* d_out_ids,
+                                        float* d_out_dist, uint32_t* d_out_n, void* hip_stream) {
+    if (!ctx || !d_keys || !d_out_ids || !d_out_dist || !d_out_n)
+        return fail(VS_E_INVALID_ARG, "null argument");
+    if (k == 0 || k > VS_MAX_K || n_lists == 0)
+        return fail(VS_E_INVALID_ARG, "k = %u or n_lists = %u out of range", k, n_lists);
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(vs::launch_merge(d_keys, n_lists, k, 1, k, metric, nullptr, d_out_ids, d_out_dist,
+                             d_out_n, static_cast<hipStream_t>(hip_stream)));
+    return VS_OK;
+}
+
+extern "C" int32_t vs_merge_topk_batch_device(vs_ctx* ctx, const uint64_t* d_keys, uint32_t n_lists,
+                                              uint64_t list_stride, uint32_t n_queries,
+                                              uint64_t query_stride, uint32_t k, int32_t metric,
+                                              uint32_t* d_out_ids, float* d_out_dist,
+                                              uint32_t* d_out_n, void* hip_stream) {
+    if (!ctx || !d_keys || !d_out_ids || !d_out_dist || !d_out_n)
+        return fail(VS_E_INVALID_ARG, "null argument");
+    if (k == 0 || k > VS_MAX_K || n_lists == 0 || n_queries == 0 || n_queries > 65535)
+        return fail(VS_E_INVALID_ARG, "k = %u, n_lists = %u or n_queries = %u out of range", k,
+                    n_lists, n_queries);
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(vs::launch_merge_batch(d_keys, n_lists, list_stride, 1, n_queries, query_stride, k,
+                                   metric, nullptr, d_out_ids, d_out_dist, d_out_n,
+                                   static_cast<hipStream_t>(hip_stream)));
+    return VS_OK;
+}

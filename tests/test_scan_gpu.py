@@ -1,0 +1,324 @@
+"""GPU parity tests of the f32 angular scan, through the C ABI (ctypes), against
+the CPU oracle on the same seeded inputs. Tolerances: tests/helpers.py."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import facet_mask, synthetic_vectors
+from helpers import check_hits
+from oracle import scan as oracle
+
+pytestmark = pytest.mark.gpu
+
+_next_index = [0]
+
+
+def make_store(ctx, vectors, docids=None, dtype=None, capacity=None, docid_base=0):
+    from search_engine_amd import abi
+    n, dim = vectors.shape
+    if docids is None:
+        docids = np.arange(n, dtype=np.uint32) + docid_base
+    _next_index[0] += 1
+    cap = capacity or int(docids.max()) - docid_base + 1
+    store = ctx.create_store(_next_index[0], dim, cap, dtype=abi.VS_F32 if dtype is None else dtype,
+                             docid_base=docid_base)
+    store.upload(docids, vectors)
+    store.seal()
+    return store
+
+
+def run_case(ctx, vectors, query, k, mask=None, docids=None, docid_base=0, store=None):
+    n = vectors.shape[0]
+    if docids is None:
+        docids = np.arange(n, dtype=np.uint32) + docid_base
+    own = store is None
+    if own:
+        store = make_store(ctx, vectors, docids, docid_base=docid_base)
+    try:
+        ids, dist = store.search(query, k, mask)
+    finally:
+        if own:
+            store.destroy()
+    o_ids, _ = oracle.nns_by_vector(vectors, query, k, docids=docids, mask=mask)
+    d64 = dict(zip(docids.tolist(), oracle.all_distances_f64(vectors, query).tolist()))
+    ok = oracle.mask_to_bool(mask, int(docids.max()) + 1)[docids] if mask is not None else np.ones(n, bool)
+    return check_hits(ids, dist, o_ids, d64, k, int(ok.sum())), ids, dist
+
+
+def test_appendix_b_known_answers(gpu_ctx):
+    """Hand-computed answers for the reference's commented-out vector scenario
+    (src/update/index_documents/mod.rs:2599-2619): query [0,1,2]."""
+    q = np.array([0, 1, 2], np.float32)
+    store0 = np.array([[0, 1, 2], [6, 7, 8], [9, 10, 11]], np.float32)  # docs 0,1,2, vector #0
+    _, ids, dist = run_case(gpu_ctx, store0, q, 10)
+    assert ids.tolist() == [0, 1, 2]
+    np.testing.assert_allclose(dist, [0.0, 0.078673, 0.088252], atol=1e-6)
+    store1 = np.array([[3, 4, 5], [12, 13, 14]], np.float32)  # docs 0 and 2, vector #1
+    _, ids, dist = run_case(gpu_ctx, store1, q, 10, docids=np.array([0, 2], np.uint32))
+    assert ids.tolist() == [0, 2]
+    np.testing.assert_allclose(dist, [0.057281, 0.093641], atol=1e-6)
+    # filter {1, 2}
+    _, ids, _ = run_case(gpu_ctx, store0, q, 10, mask=np.array([0b110], np.uint64))
+    assert ids.tolist() == [1, 2]
+
+
+@pytest.mark.parametrize("pass_percent", [None, 100, 50, 10, 1])
+def test_parity_768_filtered(gpu_ctx, pass_percent):
+    n, dim, k = 40000, 768, 10
+    vectors = synthetic_vectors(n, dim, 0xC0FFEE)
+    queries = synthetic_vectors(3, dim, 42)
+    mask = None if pass_percent is None else facet_mask(n, pass_percent)
+    store = make_store(gpu_ctx, vectors)
+    try:
+        swaps = 0
+        for q in queries:
+            s, _, _ = run_case(gpu_ctx, vectors, q, k, mask=mask, store=store)
+            swaps += s
+        assert swaps <= 1  # near ties among the top 10 of 40k random rows are rare
+    finally:
+        store.destroy()
+
+
+@pytest.mark.parametrize("dim", [1, 2, 3, 5, 100, 255, 256, 257, 384, 1024, 1536, 2048, 3072, 4096])
+def test_parity_dimensions(gpu_ctx, dim):
+    n = 3000
+    vectors = synthetic_vectors(n, dim, 7 + dim)
+    q = synthetic_vectors(1, dim, 1000 + dim)[0]
+    run_case(gpu_ctx, vectors, q, 10, mask=facet_mask(n, 50))
+
+
+@pytest.mark.parametrize("k", [1, 2, 10, 63, 64, 65, 100, 128, 129, 1000, 1024])
+def test_parity_k(gpu_ctx, k):
+    n, dim = 6000, 96
+    vectors = synthetic_vectors(n, dim, 11)
+    q = synthetic_vectors(1, dim, 12)[0]
+    run_case(gpu_ctx, vectors, q, k, mask=facet_mask(n, 50))
+
+
+def test_k_larger_than_candidates(gpu_ctx):
+    n, dim = 500, 64
+    vectors = synthetic_vectors(n, dim, 3)
+    q = synthetic_vectors(1, dim, 4)[0]
+    mask = facet_mask(n, 10)
+    _, ids, _ = run_case(gpu_ctx, vectors, q, 200, mask=mask)
+    assert ids.size == int(oracle.mask_to_bool(mask, n).sum()) < 200
+
+
+def test_empty_candidates_and_k0(gpu_ctx):
+    n, dim = 300, 32
+    vectors = synthetic_vectors(n, dim, 5)
+    q = synthetic_vectors(1, dim, 6)[0]
+    store = make_store(gpu_ctx, vectors)
+    try:
+        ids, dist = store.search(q, 10, np.zeros(5, np.uint64))
+        assert ids.size == 0 and dist.size == 0
+        ids, _ = store.search(q, 0, None)  # arroy: count == 0 -> empty
+        assert ids.size == 0
+        # a mask shorter than the docid range: docids beyond it are not candidates
+        ids, _ = store.search(q, 300, np.array([~np.uint64(0)], np.uint64))
+        assert sorted(ids.tolist()) == list(range(64))
+    finally:
+        store.destroy()
+
+
+def test_exact_ties_break_by_docid(gpu_ctx):
+    """Bit-identical rows give bit-identical distances; order must be by docid."""
+    dim = 768
+    base = synthetic_vectors(4, dim, 21)
+    vectors = np.concatenate([base[[0]]] * 40 + [base[[1]]] * 40 + [base[2:]], 0)
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(vectors.shape[0])
+    vectors = vectors[perm]
+    q = base[0] + 0.1 * base[1]
+    store = make_store(gpu_ctx, vectors)
+    try:
+        ids, dist = store.search(q, 82, None)
+    finally:
+        store.destroy()
+    o_ids, o_dist = oracle.nns_by_vector(vectors, q, 82)
+    assert ids.tolist() == o_ids.tolist()  # two runs of 40 exact ties, each ascending by docid
+    assert len(set(dist[:40].tolist())) == 1 and len(set(dist[40:80].tolist())) == 1
+    assert ids[:40].tolist() == sorted(ids[:40].tolist())
+    assert ids[40:80].tolist() == sorted(ids[40:80].tolist())
+
+
+def test_zero_norm_rows_and_query(gpu_ctx):
+    """arroy: pn * qn == 0 -> distance 0."""
+    n, dim = 200, 48
+    vectors = synthetic_vectors(n, dim, 31)
+    vectors[[5, 77, 150]] = 0.0
+    q = synthetic_vectors(1, dim, 32)[0]
+    _, ids, dist = run_case(gpu_ctx, vectors, q, 5)
+    assert ids[:3].tolist() == [5, 77, 150] and np.all(dist[:3] == 0.0)
+    _, ids, dist = run_case(gpu_ctx, vectors, np.zeros(dim, np.float32), 7)
+    assert ids.tolist() == list(range(7)) and np.all(dist == 0.0)
+
+
+def test_identical_vector_distance_near_zero(gpu_ctx):
+    n, dim = 1000, 768
+    vectors = synthetic_vectors(n, dim, 41)
+    _, ids, dist = run_case(gpu_ctx, vectors, vectors[123] * 3.5, 3)
+    assert ids[0] == 123 and abs(dist[0]) <= 1e-6
+
+
+def test_sparse_docids_base_and_removal(gpu_ctx):
+    from search_engine_amd import abi
+    dim, base = 128, 64 * 1000
+    rng = np.random.default_rng(9)
+    docids = np.sort(rng.choice(50000, 8000, replace=False)).astype(np.uint32) + base  # holes
+    vectors = synthetic_vectors(docids.size, dim, 51)
+    q = synthetic_vectors(1, dim, 52)[0]
+    mask = facet_mask(base + 50000, 50)
+    store = make_store(gpu_ctx, vectors, docids, capacity=50000, docid_base=base)
+    try:
+        assert len(store) == 8000
+        run_case(gpu_ctx, vectors, q, 20, mask=mask, docids=docids, docid_base=base, store=store)
+        # delete a third of the items, among them the current best hits
+        ids, _ = store.search(q, 20, mask)
+        gone = np.concatenate([ids[:10], docids[::3]])
+        store.remove(gone)
+        # not visible before seal (a search sees the last sealed state)
+        ids2, _ = store.search(q, 20, mask)
+        assert ids2.tolist() == ids.tolist()
+        store.seal()
+        keep = ~np.isin(docids, gone)
+        assert len(store) == int(keep.sum())
+        run_case(gpu_ctx, vectors[keep], q, 20, mask=mask, docids=docids[keep], docid_base=base,
+                 store=store)
+        assert not store.contains(int(gone[0])) and store.contains(int(docids[keep][0]))
+        np.testing.assert_array_equal(store.item_vector(int(docids[keep][5])), vectors[keep][5])
+        with pytest.raises(abi.VsError) as e:
+            store.upload(np.array([base - 1], np.uint32), vectors[:1])
+        assert e.value.code == abi.VS_E_CAPACITY
+    finally:
+        store.destroy()
+
+
+def test_overwrite_item(gpu_ctx):
+    n, dim = 400, 64
+    vectors = synthetic_vectors(n, dim, 61)
+    q = synthetic_vectors(1, dim, 62)[0]
+    store = make_store(gpu_ctx, vectors)
+    try:
+        vectors2 = vectors.copy()
+        vectors2[17] = q * 2  # becomes the best hit
+        store.upload(np.array([17], np.uint32), vectors2[[17]])
+        store.seal()
+        _, ids, _ = run_case(gpu_ctx, vectors2, q, 5, store=store)
+        assert ids[0] == 17
+    finally:
+        store.destroy()
+
+
+def test_error_codes(gpu_ctx):
+    from search_engine_amd import abi
+    vectors = synthetic_vectors(100, 16, 71)
+    with pytest.raises(abi.VsError) as e:
+        gpu_ctx.open_store(0xFFFF)  # MissingMetadata: the reader loop's terminator
+    assert e.value.code == abi.VS_E_NO_STORE
+    _next_index[0] += 1
+    store = gpu_ctx.create_store(_next_index[0], 16, 100)
+    try:
+        with pytest.raises(abi.VsError) as e:
+            gpu_ctx.open_store(_next_index[0])  # never sealed = never built
+        assert e.value.code == abi.VS_E_NO_STORE
+        store.upload(np.arange(100, dtype=np.uint32), vectors)
+        with pytest.raises(abi.VsError) as e:
+            store.search(vectors[0], 5)
+        assert e.value.code == abi.VS_E_NOT_SEALED
+        store.seal()
+        assert gpu_ctx.open_store(_next_index[0]).handle.value == store.handle.value
+        with pytest.raises(abi.VsError) as e:
+            store.search(np.zeros(17, np.float32), 5)
+        assert e.value.code == abi.VS_E_DIM_MISMATCH
+        assert (e.value.expected, e.value.received) == (16, 17)
+        with pytest.raises(abi.VsError) as e:
+            store.search(vectors[0], abi.VS_MAX_K + 1)
+        assert e.value.code == abi.VS_E_INVALID_ARG
+        with pytest.raises(abi.VsError) as e:
+            gpu_ctx.create_store(_next_index[0], 16, 100)
+        assert e.value.code == abi.VS_E_INVALID_ARG
+    finally:
+        store.destroy()
+
+
+def test_schedules_agree(gpu_ctx):
+    """Every scan schedule returns the same list bit for bit."""
+    n, dim = 30000, 384
+    vectors = synthetic_vectors(n, dim, 81)
+    q = synthetic_vectors(1, dim, 82)[0]
+    mask = facet_mask(n, 10)
+    store = make_store(gpu_ctx, vectors)
+    try:
+        results = []
+        for mp, blocks, nt in [(0, 0, 0), (1, 0, 0), (0, 7, 1), (1, 300, 1), (0, 1024, 0)]:
+            gpu_ctx.set_scan_tuning(mp, blocks, nt)
+            ids, dist = store.search(q, 50, mask)
+            results.append((ids.tolist(), dist.tolist()))
+        assert all(r == results[0] for r in results[1:])
+    finally:
+        gpu_ctx.set_scan_tuning(0, 0, 0)
+        store.destroy()
+
+
+def test_search_batch_and_roaring(gpu_ctx):
+    from search_engine_amd import abi
+    n, dim = 70000 + 13, 64
+    vectors = synthetic_vectors(n, dim, 91)
+    queries = synthetic_vectors(5, dim, 92)
+    mask = facet_mask(n, 10)
+    mask[0:1024] = ~np.uint64(0)  # one full container -> bitmap container in roaring form
+    store = make_store(gpu_ctx, vectors)
+    try:
+        single = [store.search(q, 10, mask) for q in queries]
+        batch = store.search_batch(queries, 10, mask)
+        blob = abi.mask_to_roaring(mask)
+        for (i1, d1), (i2, d2), q in zip(single, batch, queries):
+            assert i1.tolist() == i2.tolist() and d1.tolist() == d2.tolist()
+            i3, d3 = store.search_roaring(q, 10, blob)
+            assert i1.tolist() == i3.tolist() and d1.tolist() == d3.tolist()
+        with pytest.raises(abi.VsError) as e:
+            store.search_roaring(queries[0], 10, b"\x01\x02\x03\x04\x05\x06\x07\x08\x09")
+        assert e.value.code == abi.VS_E_FORMAT
+    finally:
+        store.destroy()
+
+
+def test_device_api_and_shard_merge(gpu_ctx):
+    """Two docid-range shards searched through the device entry point, keys
+    concatenated as an all-gather would, merged: identical to one store."""
+    import torch
+    from search_engine_amd import abi
+    n, dim, k = 64 * 500, 128, 10
+    vectors = synthetic_vectors(n, dim, 101)
+    q = synthetic_vectors(1, dim, 102)[0]
+    mask = facet_mask(n, 50)
+    half = n // 2
+    whole = make_store(gpu_ctx, vectors)
+    a = make_store(gpu_ctx, vectors[:half])
+    b = make_store(gpu_ctx, vectors[half:], docid_base=half)
+    try:
+        ref_ids, ref_dist = whole.search(q, k, mask)
+        dev = torch.device("cuda:0")
+        d_q = torch.from_numpy(q).to(dev)
+        d_mask = torch.from_numpy(mask.view(np.int64)).to(dev)
+        keys = torch.empty(2 * k, dtype=torch.int64, device=dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        for j, st in enumerate((a, b)):
+            ws = torch.empty(st.workspace_bytes(k), dtype=torch.uint8, device=dev)
+            words0 = (j * half) // 64
+            st.search_device(d_q.data_ptr(), dim, k, d_mask.data_ptr() + 8 * words0, ws.data_ptr(),
+                             keys.data_ptr() + 8 * k * j, stream)
+        ids = torch.empty(k, dtype=torch.int32, device=dev)
+        dist = torch.empty(k, dtype=torch.float32, device=dev)
+        cnt = torch.empty(1, dtype=torch.int32, device=dev)
+        gpu_ctx.merge_topk_device(keys.data_ptr(), 2, k, abi.VS_ANGULAR, ids.data_ptr(),
+                                  dist.data_ptr(), cnt.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert cnt.item() == k
+        assert ids.cpu().numpy().astype(np.uint32).tolist() == ref_ids.tolist()
+        assert dist.cpu().numpy().tolist() == ref_dist.tolist()
+    finally:
+        for st in (whole, a, b):
+            st.destroy()
