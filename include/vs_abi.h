@@ -79,11 +79,10 @@ int32_t vs_last_error(vs_ctx* ctx, char* buf, size_t cap);
 int32_t vs_last_dim_mismatch(vs_ctx* ctx, uint32_t* expected, uint32_t* received);
 
 /* Scan schedule knobs, for measurement only (no reference counterpart; results
- * do not depend on them). map: 0 = slots dealt round-robin over the waves,
- * 1 = 64-slot mask words dealt round-robin; blocks: grid size, 0 = default;
- * nt: non-zero = non-temporal row loads. Also read once from the environment
- * (VS_SCAN_MAP, VS_SCAN_BLOCKS, VS_SCAN_NT) by vs_init. */
-int32_t vs_set_scan_tuning(vs_ctx* ctx, int32_t map, int32_t blocks, int32_t nt);
+ * do not depend on them). blocks: grid size, 0 = default; nt: non-zero =
+ * non-temporal row loads (the default), 0 = plain loads. Also read once from
+ * the environment (VS_SCAN_BLOCKS, VS_SCAN_NT) by vs_init. */
+int32_t vs_set_scan_tuning(vs_ctx* ctx, int32_t blocks, int32_t nt);
 
 /* ---- stores ------------------------------------------------------------- */
 

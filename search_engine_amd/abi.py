@@ -35,7 +35,7 @@ SIGNATURES = {
     "vs_shutdown": [_vp],
     "vs_last_error": [_vp, ctypes.c_char_p, _sz],
     "vs_last_dim_mismatch": [_vp, _u32p, _u32p],
-    "vs_set_scan_tuning": [_vp, _i32, _i32, _i32],
+    "vs_set_scan_tuning": [_vp, _i32, _i32],
     "vs_store_create": [_vp, _u16, _u32, _i32, _i32, _u32, _u64, ctypes.POINTER(_vp)],
     "vs_store_open": [_vp, _u16, ctypes.POINTER(_vp)],
     "vs_store_upload": [_vp, _u32p, _f32p, _u64],
@@ -139,8 +139,8 @@ class Context:
     def __exit__(self, *exc):
         self.close()
 
-    def set_scan_tuning(self, map=0, blocks=0, nt=0):
-        _check(lib.vs_set_scan_tuning(self.handle, map, blocks, nt), self.handle)
+    def set_scan_tuning(self, blocks=0, nt=1):
+        _check(lib.vs_set_scan_tuning(self.handle, blocks, nt), self.handle)
 
     def create_store(self, index, dim, capacity, dtype=VS_F32, metric=VS_ANGULAR, docid_base=0):
         h = _vp()

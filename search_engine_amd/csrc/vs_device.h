@@ -118,4 +118,73 @@ __device__ __forceinline__ uint64_t list_insert(volatile uint64_t* list, int k, 
     return uniform_u64(list[k - 1]);
 }
 
+// lane i receives lane i-1's value (lane 0 receives `fill`): DPP wave_shr:1
+__device__ __forceinline__ uint64_t wave_shift_up_u64(uint64_t v, uint64_t fill) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)fill, (int)(uint32_t)v,
+                                                              0x138, 0xF, 0xF, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(
+        (int)(uint32_t)(fill >> 32), (int)(uint32_t)(v >> 32), 0x138, 0xF, 0xF, false);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// The k smallest keys one wave has seen, ascending. For k <= 64 the list lives in
+// a register pair (lane i holds the i-th smallest) and an insert is a compare, a
+// ballot and one cross-lane shift; larger k use the LDS list above. `tau` is the
+// k-th smallest so far (KEY_NONE while fewer than k keys are held): only keys
+// below it may be inserted.
+struct WaveTopK {
+    volatile uint64_t* lds;  // k entries owned by this wave
+    int k, lane;
+    bool in_regs;
+    uint64_t mine;
+    uint64_t tau;
+
+    __device__ __forceinline__ void init(volatile uint64_t* lds_, int k_, int lane_) {
+        lds = lds_;
+        k = k_;
+        lane = lane_;
+        in_regs = k_ <= 64;
+        mine = KEY_NONE;
+        tau = KEY_NONE;
+        if (!in_regs) {
+            for (int i = lane; i < k; i += 64) lds[i] = KEY_NONE;
+            wave_lds_fence();
+        }
+    }
+    // `key` is wave-uniform and < tau
+    __device__ __forceinline__ void insert(uint64_t key) {
+        if (in_regs) {
+            const int pos = __popcll(__ballot(mine < key));
+            const uint64_t up = wave_shift_up_u64(mine, KEY_NONE);
+            mine = lane < pos ? mine : (lane == pos ? key : up);
+            if (lane >= k) mine = KEY_NONE;
+            tau = readlane_u64(mine, k - 1);
+        } else {
+            tau = list_insert(lds, k, key, lane);
+        }
+    }
+    // after this the list can be read from `lds` (by this wave, or by others
+    // after a workgroup barrier)
+    __device__ __forceinline__ void spill() {
+        if (in_regs) {
+            if (lane < k) lds[lane] = mine;
+            wave_lds_fence();
+        }
+    }
+    // inserts every entry below tau of another wave's spilled list
+    __device__ __forceinline__ void absorb(volatile uint64_t* other) {
+        for (int j = 0; j < k; ++j) {
+            const uint64_t key = uniform_u64(other[j]);
+            if (key >= tau) break;
+            insert(key);
+        }
+    }
+    // i-th smallest for i = base + lane, valid for i < k
+    __device__ __forceinline__ uint64_t at_lane(int base) const {
+        if (in_regs) return mine;  // base == 0
+        const int i = base + lane;
+        return i < k ? lds[i] : KEY_NONE;
+    }
+};
+
 }  // namespace vs

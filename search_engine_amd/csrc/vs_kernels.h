@@ -24,12 +24,12 @@ struct SlabView {
 // Scan tuning knobs (0 = library default); exposed so the benchmark can A/B
 // schedules in one process.
 struct ScanTuning {
-    int32_t map;     // 0: rows interleaved over waves, 1: 64-row words per wave
-    int32_t blocks;  // grid size
-    int32_t nt;      // 1: non-temporal row loads
+    int32_t blocks;  // grid size, 0 = default
+    int32_t nt;      // non-zero: non-temporal row loads (the default)
+    int32_t rows_in_flight = 0;  // rows one wave loads before it scores them, 0 = default
 };
 
-uint32_t scan_grid_blocks(const SlabView& s, const ScanTuning& t);
+uint32_t scan_grid_blocks(const SlabView& s, const ScanTuning& t, bool masked);
 // device bytes of the partial-list buffer one scan of this slab writes
 uint64_t scan_partial_bytes(const SlabView& s, uint32_t k, const ScanTuning& t);
 

@@ -26,9 +26,8 @@
 namespace vs {
 
 constexpr int WAVES = 4;               // waves per workgroup
-constexpr int SB = 4;                  // 64-candidate mask batches per queue refill
-constexpr int QCAP = SB * 64 + 16;     // row queue entries per wave
-constexpr uint32_t MAX_BLOCKS = 1024;  // 4 workgroups on each of the 256 CUs
+constexpr int QCAP = 64 + 16;          // row queue entries per wave: one mask word + leftovers
+constexpr uint32_t NUM_CUS = 256;       // MI355X
 
 struct ScanArgs {
     const u32x4* rows;
@@ -46,23 +45,6 @@ struct ScanArgs {
 
 __device__ __forceinline__ uint32_t lanes_below(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-}
-
-// i-th candidate slot of wave `w` out of `W`.
-//   MAP 0: slots are dealt round-robin over the waves (wave w owns w, w+W, ...):
-//          at any moment the whole chip reads one contiguous window of the slab.
-//   MAP 1: 64-slot words are dealt round-robin (wave w owns words w, w+W, ...):
-//          one mask word per 64 candidates, each wave streams 64 adjacent rows.
-template <int MAP>
-__device__ __forceinline__ uint64_t slot_of(uint64_t i, uint32_t w, uint32_t W) {
-    if (MAP == 0) return i * W + w;
-    return ((((i >> 6) * W) + w) << 6) | (i & 63);
-}
-template <int MAP>
-__device__ __forceinline__ uint64_t slots_of_wave(uint64_t n_slots, uint32_t w, uint32_t W) {
-    if (MAP == 0) return w < n_slots ? (n_slots - w + W - 1) / W : 0;
-    const uint64_t n_words = n_slots >> 6;
-    return w < n_words ? ((n_words - w + W - 1) / W) << 6 : 0;
 }
 
 // Elements of one 16-byte row vector: 4 f32 or 8 bf16.
@@ -123,7 +105,7 @@ __device__ __forceinline__ float angular_distance(float pq, float pn, float qn) 
     return 0.0f;
 }
 
-template <int ELEM, int NCH, int U, int MAP, bool NT>
+template <int ELEM, int NCH, int U, bool NT>
 __global__ __launch_bounds__(WAVES * 64) void scan_angular_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int EPV = Epv<ELEM>::value;
@@ -133,11 +115,10 @@ __global__ __launch_bounds__(WAVES * 64) void scan_angular_kernel(ScanArgs a) {
     const uint32_t w = blockIdx.x * WAVES + wib;
     const int k = (int)a.k;
 
-    volatile uint64_t* list = reinterpret_cast<volatile uint64_t*>(smem) + (size_t)wib * k;
     volatile uint32_t* queue =
         reinterpret_cast<volatile uint32_t*>(smem + (size_t)WAVES * k * 8) + (size_t)wib * QCAP;
-    for (int i = lane; i < k; i += 64) list[i] = KEY_NONE;
-    uint64_t tau = KEY_NONE;
+    WaveTopK top;
+    top.init(reinterpret_cast<volatile uint64_t*>(smem) + (size_t)wib * k, k, lane);
 
     // this lane's slice of the query, and ‖q‖ summed in the row order
     float q[NCH][EPV];
@@ -186,71 +167,85 @@ __global__ __launch_bounds__(WAVES * 64) void scan_angular_kernel(ScanArgs a) {
             const float pq = wave_sum_f32(acc);
             const float d = angular_distance(pq, pn[u], qn);
             const uint64_t key = make_key(uniform_u32(f32_orderable(d)), a.docid_base + slot[u]);
-            if ((uint32_t)u < nvalid && key < tau) tau = list_insert(list, k, key, lane);
+            if ((uint32_t)u < nvalid && key < top.tau) top.insert(key);
         }
     };
 
-    const uint64_t n_i = slots_of_wave<MAP>(a.n_slots, w, W);
+    // The wave owns the 64-slot mask words w, w + W, w + 2W, ... Each lane fetches
+    // one of the next 64 of them (the following batch is requested before this
+    // one is scored); words with a set bit are then taken one at a time, their
+    // passing slots appended to the queue, and the queue is scored U rows at a time.
+    const uint64_t n_words = a.n_slots >> 6;
+    const uint64_t my_words = w < n_words ? (n_words - w + W - 1) / W : 0;
+    auto fetch_words = [&](uint64_t t0) -> uint64_t {
+        const uint64_t t = t0 + (uint64_t)lane;
+        uint64_t wd = 0;
+        if (t < my_words) {
+            const uint64_t wi = (uint64_t)w + t * W;
+            wd = a.present[wi];
+            if (a.cand) wd &= a.cand[wi];
+        }
+        return wd;
+    };
     uint32_t qcount = 0;
-    for (uint64_t i0 = 0; i0 < n_i; i0 += SB * 64) {
-        // refill the queue with the slots of the next SB * 64 candidates that pass
-#pragma unroll
-        for (int b = 0; b < SB; ++b) {
-            const uint64_t i = i0 + (uint64_t)(b * 64 + lane);
-            bool pass = false;
-            uint32_t slot = 0;
-            if (i < n_i) {
-                const uint64_t s = slot_of<MAP>(i, w, W);
-                uint64_t wd = a.present[s >> 6];
-                if (a.cand) wd &= a.cand[s >> 6];
-                pass = (wd >> (s & 63)) & 1;
-                slot = (uint32_t)s;
+    uint64_t wd_next = fetch_words(0);
+    for (uint64_t t0 = 0; t0 < my_words; t0 += 64) {
+        const uint64_t wd = wd_next;
+        if (t0 + 64 < my_words) wd_next = fetch_words(t0 + 64);
+        uint64_t nz = __ballot(wd != 0);
+        while (nz) {
+            const int b = __builtin_ctzll(nz);
+            nz &= nz - 1;
+            const uint64_t word = readlane_u64(wd, b);
+            const uint32_t slot0 = (uint32_t)(((uint64_t)w + (t0 + (uint64_t)b) * W) << 6);
+            if ((word >> lane) & 1) queue[qcount + lanes_below(word)] = slot0 + (uint32_t)lane;
+            qcount += (uint32_t)__popcll(word);
+            wave_lds_fence();
+            if (qcount >= (uint32_t)U) {
+                uint32_t head = 0;
+                do {
+                    score_rows(head, U);
+                    head += U;
+                } while (qcount - head >= (uint32_t)U);
+                // keep the (< U) leftovers at the front
+                const uint32_t rem = qcount - head;
+                uint32_t v = 0;
+                if ((uint32_t)lane < rem) v = queue[head + lane];
+                wave_lds_fence();
+                if ((uint32_t)lane < rem) queue[lane] = v;
+                wave_lds_fence();
+                qcount = rem;
             }
-            const uint64_t m = __ballot(pass);
-            if (pass) queue[qcount + lanes_below(m)] = slot;
-            qcount += (uint32_t)__popcll(m);
         }
-        wave_lds_fence();
-        uint32_t head = 0;
-        while (qcount - head >= (uint32_t)U) {
-            score_rows(head, U);
-            head += U;
-        }
-        // keep the (< U) leftovers for the next round
-        const uint32_t rem = qcount - head;
-        uint32_t v = 0;
-        if ((uint32_t)lane < rem) v = queue[head + lane];
-        wave_lds_fence();
-        if ((uint32_t)lane < rem) queue[lane] = v;
-        wave_lds_fence();
-        qcount = rem;
     }
     if (qcount) score_rows(0, qcount);
 
     // workgroup merge: wave 0 absorbs the other waves' lists
+    top.spill();
     __syncthreads();
     if (wib == 0) {
-        for (int v = 1; v < WAVES; ++v) {
-            volatile uint64_t* other = reinterpret_cast<volatile uint64_t*>(smem) + (size_t)v * k;
-            for (int j = 0; j < k; ++j) {
-                const uint64_t key = uniform_u64(other[j]);
-                if (key >= tau) break;
-                tau = list_insert(list, k, key, lane);
-            }
+        for (int v = 1; v < WAVES; ++v)
+            top.absorb(reinterpret_cast<volatile uint64_t*>(smem) + (size_t)v * k);
+        for (int base = 0; base < k; base += 64) {
+            const int i = base + lane;
+            const uint64_t key = top.at_lane(base);
+            if (i < k) a.partial[(uint64_t)i * gridDim.x + blockIdx.x] = key;
         }
-        for (int i = lane; i < k; i += 64)
-            a.partial[(uint64_t)i * gridDim.x + blockIdx.x] = list[i];
     }
 }
 
 // ---- merge of sorted key lists ------------------------------------------------
 
 // One workgroup per query: blockIdx.x selects the query's key lists
-// (keys + blockIdx.x * query_stride) and its slice of every output.
+// (keys + blockIdx.x * query_stride) and its slice of every output. Entry r of
+// list l is keys[l * list_stride + r * rank_stride], r < n_ranks; every list is
+// ascending. The four waves each merge a quarter of the lists into a WaveTopK,
+// rank by rank with the next rank's keys already requested, then wave 0 absorbs
+// the other three.
 __global__ __launch_bounds__(256) void merge_kernel(const uint64_t* keys, uint32_t n_lists,
                                                     uint64_t list_stride, uint64_t rank_stride,
-                                                    uint64_t query_stride, uint32_t k_,
-                                                    int32_t metric, uint64_t* out_keys,
+                                                    uint32_t n_ranks, uint64_t query_stride,
+                                                    uint32_t k_, int32_t metric, uint64_t* out_keys,
                                                     uint32_t* out_ids, float* out_dist,
                                                     uint32_t* out_n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -264,51 +259,52 @@ __global__ __launch_bounds__(256) void merge_kernel(const uint64_t* keys, uint32
     const int lane = threadIdx.x & 63;
     const uint32_t wv = uniform_u32(threadIdx.x >> 6);
     const int k = (int)k_;
-    volatile uint64_t* list = reinterpret_cast<volatile uint64_t*>(smem) + (size_t)wv * k;
-    for (int i = lane; i < k; i += 64) list[i] = KEY_NONE;
-    wave_lds_fence();
-    uint64_t tau = KEY_NONE;
+    WaveTopK top;
+    top.init(reinterpret_cast<volatile uint64_t*>(smem) + (size_t)wv * k, k, lane);
 
-    // Every input list is ascending, so once no list of this wave has its
-    // rank-r entry below tau, no later rank can have one either.
-    for (int r = 0; r < k; ++r) {
-        bool any = false;
-        for (uint32_t base = 0; base < n_lists; base += 1024) {
-            uint64_t key[4];
+    for (uint32_t base = 0; base < n_lists; base += 1024) {
+        auto load_rank = [&](uint32_t r, uint64_t (&dst)[4]) {
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const uint32_t l = base + (uint32_t)b * 256 + wv * 64 + lane;
-                key[b] = l < n_lists ? keys[(uint64_t)l * list_stride + (uint64_t)r * rank_stride]
+                dst[b] = l < n_lists ? keys[(uint64_t)l * list_stride + (uint64_t)r * rank_stride]
                                      : KEY_NONE;
             }
+        };
+        uint64_t nxt[4];
+        load_rank(0, nxt);
+        // Once no list of this wave has its rank-r entry below tau, no later
+        // rank can have one either.
+        for (uint32_t r = 0; r < n_ranks; ++r) {
+            uint64_t key[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) key[b] = nxt[b];
+            if (r + 1 < n_ranks) load_rank(r + 1, nxt);
+            bool any = false;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                uint64_t m = __ballot(key[b] < tau);
+                uint64_t m = __ballot(key[b] < top.tau);
                 while (m) {
                     const int src = __builtin_ctzll(m);
-                    tau = list_insert(list, k, readlane_u64(key[b], src), lane);
+                    top.insert(readlane_u64(key[b], src));
                     any = true;
                     m &= m - 1;
-                    m &= __ballot(key[b] < tau);
+                    m &= __ballot(key[b] < top.tau);
                 }
             }
+            if (!any) break;
         }
-        if (!any) break;
     }
+    top.spill();
     __syncthreads();
     if (wv == 0) {
-        for (int v = 1; v < 4; ++v) {
-            volatile uint64_t* other = reinterpret_cast<volatile uint64_t*>(smem) + (size_t)v * k;
-            for (int j = 0; j < k; ++j) {
-                const uint64_t key = uniform_u64(other[j]);
-                if (key >= tau) break;
-                tau = list_insert(list, k, key, lane);
-            }
-        }
+        for (int v = 1; v < 4; ++v)
+            top.absorb(reinterpret_cast<volatile uint64_t*>(smem) + (size_t)v * k);
         uint32_t n = 0;
         for (int base = 0; base < k; base += 64) {
             const int i = base + lane;
-            const uint64_t key = i < k ? list[i] : KEY_NONE;
+            uint64_t key = top.at_lane(base);
+            if (i >= k) key = KEY_NONE;
             if (i < k) {
                 if (out_keys) out_keys[i] = key;
                 if (out_ids) {
@@ -418,31 +414,30 @@ __global__ __launch_bounds__(256) void roaring_expand_kernel(const uint8_t* byte
 
 // ---- launchers ------------------------------------------------------------------------
 
-uint32_t scan_grid_blocks(const SlabView& s, const ScanTuning& t) {
+// Default grid, measured on 10M x 768 f32 rows: an unfiltered scan is fastest
+// with one workgroup per CU (one wave per SIMD, 4 rows = 12 KiB in flight per
+// wave); with a candidate mask two workgroups per CU win, because one wave's
+// mask decoding then overlaps another's row loads. More waves lose bandwidth.
+uint32_t scan_grid_blocks(const SlabView& s, const ScanTuning& t, bool masked) {
     if (t.blocks > 0) return (uint32_t)t.blocks;
     const uint64_t want = (s.n_slots + 1023) / 1024;  // >= 256 slots per wave
-    return (uint32_t)(want < 1 ? 1 : want > MAX_BLOCKS ? MAX_BLOCKS : want);
+    const uint64_t cap = masked ? 2 * NUM_CUS : NUM_CUS;
+    return (uint32_t)(want < 1 ? 1 : want > cap ? cap : want);
 }
 
 uint64_t scan_partial_bytes(const SlabView& s, uint32_t k, const ScanTuning& t) {
-    return (uint64_t)scan_grid_blocks(s, t) * k * sizeof(uint64_t);
+    const uint32_t a = scan_grid_blocks(s, t, true), b = scan_grid_blocks(s, t, false);
+    return (uint64_t)(a > b ? a : b) * k * sizeof(uint64_t);
 }
 
 template <int ELEM, int NCH, int U>
 static hipError_t launch_scan_t(const ScanArgs& a, uint32_t blocks, size_t lds, const ScanTuning& t,
                                 hipStream_t stream) {
     const dim3 grid(blocks), block(WAVES * 64);
-    if (t.map == 0) {
-        if (t.nt)
-            hipLaunchKernelGGL((scan_angular_kernel<ELEM, NCH, U, 0, true>), grid, block, lds, stream, a);
-        else
-            hipLaunchKernelGGL((scan_angular_kernel<ELEM, NCH, U, 0, false>), grid, block, lds, stream, a);
-    } else {
-        if (t.nt)
-            hipLaunchKernelGGL((scan_angular_kernel<ELEM, NCH, U, 1, true>), grid, block, lds, stream, a);
-        else
-            hipLaunchKernelGGL((scan_angular_kernel<ELEM, NCH, U, 1, false>), grid, block, lds, stream, a);
-    }
+    if (t.nt)
+        hipLaunchKernelGGL((scan_angular_kernel<ELEM, NCH, U, true>), grid, block, lds, stream, a);
+    else
+        hipLaunchKernelGGL((scan_angular_kernel<ELEM, NCH, U, false>), grid, block, lds, stream, a);
     return hipGetLastError();
 }
 
@@ -452,7 +447,11 @@ static hipError_t launch_scan_e(const ScanArgs& a, uint32_t blocks, size_t lds, 
     const uint32_t nch = (a.row_vecs + 63) / 64;
     if (nch <= 1) return launch_scan_t<ELEM, 1, 8>(a, blocks, lds, t, stream);
     if (nch <= 2) return launch_scan_t<ELEM, 2, 8>(a, blocks, lds, t, stream);
-    if (nch <= 3) return launch_scan_t<ELEM, 3, 4>(a, blocks, lds, t, stream);
+    if (nch <= 3) {
+        if (t.rows_in_flight == 2) return launch_scan_t<ELEM, 3, 2>(a, blocks, lds, t, stream);
+        if (t.rows_in_flight == 8) return launch_scan_t<ELEM, 3, 8>(a, blocks, lds, t, stream);
+        return launch_scan_t<ELEM, 3, 4>(a, blocks, lds, t, stream);
+    }
     if (nch <= 4) return launch_scan_t<ELEM, 4, 4>(a, blocks, lds, t, stream);
     if (nch <= 6) return launch_scan_t<ELEM, 6, 2>(a, blocks, lds, t, stream);
     if (nch <= 8) return launch_scan_t<ELEM, 8, 2>(a, blocks, lds, t, stream);
@@ -478,7 +477,7 @@ hipError_t launch_scan_angular(const SlabView& s, const float* d_query, const ui
     a.dim = s.dim;
     a.docid_base = s.docid_base;
     a.k = k;
-    const uint32_t blocks = scan_grid_blocks(s, t);
+    const uint32_t blocks = scan_grid_blocks(s, t, cand != nullptr);
     const size_t lds = (size_t)WAVES * k * 8 + (size_t)WAVES * QCAP * 4;
     hipError_t e;
     if (s.dtype == VS_F32)
@@ -504,9 +503,21 @@ hipError_t launch_merge_batch(const uint64_t* keys, uint32_t n_lists, uint64_t l
                               uint32_t k, int32_t metric, uint64_t* out_keys, uint32_t* out_ids,
                               float* out_dist, uint32_t* out_n, hipStream_t stream) {
     if (k == 0 || k > VS_MAX_K || n_lists == 0 || n_queries == 0) return hipErrorInvalidValue;
+    uint32_t n_ranks = k;
+    // Few keys in one contiguous run (lists back to back, or the rank-major
+    // partial buffer): treat every key as a list of its own, so that all of them
+    // are requested at once instead of rank after rank.
+    const uint64_t total = (uint64_t)n_lists * k;
+    if (total <= 4096 &&
+        ((rank_stride == 1 && list_stride == k) || (list_stride == 1 && rank_stride == n_lists))) {
+        n_lists = (uint32_t)total;
+        list_stride = 1;
+        rank_stride = 0;
+        n_ranks = 1;
+    }
     hipLaunchKernelGGL(merge_kernel, dim3(n_queries), dim3(256), (size_t)4 * k * 8, stream, keys,
-                       n_lists, list_stride, rank_stride, query_stride, k, metric, out_keys, out_ids,
-                       out_dist, out_n);
+                       n_lists, list_stride, rank_stride, n_ranks, query_stride, k, metric, out_keys,
+                       out_ids, out_dist, out_n);
     return hipGetLastError();
 }
 

@@ -84,7 +84,7 @@ struct vs_ctx {
     std::mutex mu;  // stores map, pool, staging
     std::map<uint16_t, vs_store*> stores;
     std::vector<std::unique_ptr<Workspace>> pool;
-    vs::ScanTuning tuning{0, 0, 0};
+    vs::ScanTuning tuning{0, 1};
     // upload staging (guarded by upload_mu)
     std::mutex upload_mu;
     unsigned char* h_stage = nullptr;
@@ -263,9 +263,9 @@ extern "C" int32_t vs_init(int32_t device_ordinal, vs_ctx** out) {
                     device_ordinal, prop.gcnArchName);
     std::unique_ptr<vs_ctx> ctx(new vs_ctx());
     ctx->device = device_ordinal;
-    if (const char* v = getenv("VS_SCAN_MAP")) ctx->tuning.map = atoi(v);
     if (const char* v = getenv("VS_SCAN_BLOCKS")) ctx->tuning.blocks = atoi(v);
     if (const char* v = getenv("VS_SCAN_NT")) ctx->tuning.nt = atoi(v);
+    if (const char* v = getenv("VS_SCAN_ROWS")) ctx->tuning.rows_in_flight = atoi(v);
     HIP_TRY(hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
     *out = ctx.release();
     return VS_OK;
@@ -301,11 +301,11 @@ extern "C" int32_t vs_last_dim_mismatch(vs_ctx*, uint32_t* expected, uint32_t* r
     return VS_OK;
 }
 
-extern "C" int32_t vs_set_scan_tuning(vs_ctx* ctx, int32_t map, int32_t blocks, int32_t nt) {
+extern "C" int32_t vs_set_scan_tuning(vs_ctx* ctx, int32_t blocks, int32_t nt) {
     if (!ctx) return fail(VS_E_INVALID_ARG, "null context");
-    if (map < 0 || map > 1 || blocks < 0 || blocks > 65535)
-        return fail(VS_E_INVALID_ARG, "bad tuning values");
-    ctx->tuning = vs::ScanTuning{map, blocks, nt ? 1 : 0};
+    if (blocks < 0 || blocks > 65535) return fail(VS_E_INVALID_ARG, "bad tuning values");
+    ctx->tuning.blocks = blocks;
+    ctx->tuning.nt = nt ? 1 : 0;
     return VS_OK;
 }
 

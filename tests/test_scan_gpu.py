@@ -252,13 +252,13 @@ def test_schedules_agree(gpu_ctx):
     store = make_store(gpu_ctx, vectors)
     try:
         results = []
-        for mp, blocks, nt in [(0, 0, 0), (1, 0, 0), (0, 7, 1), (1, 300, 1), (0, 1024, 0)]:
-            gpu_ctx.set_scan_tuning(mp, blocks, nt)
+        for blocks, nt in [(0, 1), (0, 0), (7, 1), (300, 0), (2048, 1)]:
+            gpu_ctx.set_scan_tuning(blocks, nt)
             ids, dist = store.search(q, 50, mask)
             results.append((ids.tolist(), dist.tolist()))
         assert all(r == results[0] for r in results[1:])
     finally:
-        gpu_ctx.set_scan_tuning(0, 0, 0)
+        gpu_ctx.set_scan_tuning(0, 1)
         store.destroy()
 
 
