@@ -116,34 +116,32 @@ def main():
     qgen.manual_seed(42)
     queries = torch.randn(1024, dim, generator=qgen, device=dev, dtype=torch.float32)
     n_slots = -(-max(n_local, 64) // 64) * 64
-    ws = torch.empty(store.workspace_bytes(k), dtype=torch.uint8, device=dev)
-    keys = torch.empty(qps_batch * k, dtype=torch.int64, device=dev)
-    gathered = torch.empty(world * qps_batch * k, dtype=torch.int64, device=dev)
-    out_ids = torch.empty(qps_batch * k, dtype=torch.int32, device=dev)
-    out_dist = torch.empty(qps_batch * k, dtype=torch.float32, device=dev)
-    out_n = torch.empty(qps_batch, dtype=torch.int32, device=dev)
     row_bytes = store.row_bytes
+    from search_engine_amd import sharded
+    cur = {"step": 0, "mask": None, "events": None}
+    searcher = sharded.gpu_sharded_search(
+        ctx, store, k, qps_batch, dev,
+        query_ptr=lambda j: queries[(cur["step"] * qps_batch + j) % 1024].data_ptr(),
+        mask_ptr=lambda: cur["mask"].data_ptr(), stream=lambda: stream)
+    plain_local_search = searcher.local_search
+
+    def timed_local_search(j, out_keys):
+        # events on the stream the scan is launched on (torch's current stream)
+        if cur["events"] is None:
+            return plain_local_search(j, out_keys)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        plain_local_search(j, out_keys)
+        e1.record()
+        cur["events"].append((e0, e1))
+
+    searcher.local_search = timed_local_search
+    out = {}
 
     def step(i, mask, events=None):
-        for j in range(qps_batch):
-            q = queries[(i * qps_batch + j) % 1024]
-            if events is not None:
-                e0 = torch.cuda.Event(enable_timing=True)
-                e1 = torch.cuda.Event(enable_timing=True)
-                e0.record()
-            store.search_device(q.data_ptr(), dim, k, mask.data_ptr(), ws.data_ptr(),
-                                keys.data_ptr() + 8 * k * j, stream)
-            if events is not None:
-                e1.record()
-                events.append((e0, e1))
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, keys)
-            src = gathered
-        else:
-            src = keys
-        ctx.merge_topk_batch_device(src.data_ptr(), world, qps_batch * k, qps_batch, k, k,
-                                    abi.VS_ANGULAR, out_ids.data_ptr(), out_dist.data_ptr(),
-                                    out_n.data_ptr(), stream)
+        cur.update(step=i, mask=mask, events=events)
+        out["ids"], out["dist"], out["n"] = searcher.run()
 
     def barrier():
         if world > 1:
@@ -191,8 +189,8 @@ def main():
 
     # sanity: the last batch's results are well-formed (k hits, ascending)
     torch.cuda.synchronize()
-    d = out_dist.view(qps_batch, k).cpu().numpy()
-    assert (out_n.cpu().numpy() == k).all() and (np.diff(d, axis=1) >= 0).all(), "malformed results"
+    d = out["dist"].view(qps_batch, k).cpu().numpy()
+    assert (out["n"].cpu().numpy() == k).all() and (np.diff(d, axis=1) >= 0).all(), "malformed results"
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,618 @@
+// C++ mirror of the reference's host logic on the vector-search path; see
+// host_engine.h for the map onto the reference's files. CPU control flow only.
+#include "host_engine.h"
+
+#include <algorithm>
+#include <charconv>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+#include "../../include/vs_abi.h"
+
+namespace search_engine {
+
+// ---- DocSet -------------------------------------------------------------------------
+
+DocSet DocSet::from_ids(const std::vector<DocumentId>& ids) {
+    DocSet s;
+    for (DocumentId d : ids) s.insert(d);
+    return s;
+}
+DocSet DocSet::from_words(std::vector<uint64_t> words) {
+    DocSet s;
+    s.w_ = std::move(words);
+    return s;
+}
+bool DocSet::contains(DocumentId d) const {
+    const size_t wi = d >> 6;
+    return wi < w_.size() && ((w_[wi] >> (d & 63)) & 1);
+}
+bool DocSet::insert(DocumentId d) {
+    const size_t wi = d >> 6;
+    if (wi >= w_.size()) w_.resize(wi + 1, 0);
+    const uint64_t bit = 1ull << (d & 63);
+    const bool fresh = !(w_[wi] & bit);
+    w_[wi] |= bit;
+    return fresh;
+}
+bool DocSet::remove(DocumentId d) {
+    const size_t wi = d >> 6;
+    if (wi >= w_.size()) return false;
+    const uint64_t bit = 1ull << (d & 63);
+    const bool had = w_[wi] & bit;
+    w_[wi] &= ~bit;
+    return had;
+}
+uint64_t DocSet::len() const {
+    uint64_t n = 0;
+    for (uint64_t w : w_) n += (uint64_t)__builtin_popcountll(w);
+    return n;
+}
+bool DocSet::is_empty() const {
+    for (uint64_t w : w_)
+        if (w) return false;
+    return true;
+}
+DocSet DocSet::operator&(const DocSet& o) const {
+    DocSet r;
+    r.w_.resize(std::min(w_.size(), o.w_.size()));
+    for (size_t i = 0; i < r.w_.size(); ++i) r.w_[i] = w_[i] & o.w_[i];
+    return r;
+}
+DocSet DocSet::operator|(const DocSet& o) const {
+    DocSet r = *this;
+    r |= o;
+    return r;
+}
+DocSet& DocSet::operator|=(const DocSet& o) {
+    if (o.w_.size() > w_.size()) w_.resize(o.w_.size(), 0);
+    for (size_t i = 0; i < o.w_.size(); ++i) w_[i] |= o.w_[i];
+    return *this;
+}
+DocSet& DocSet::operator-=(const DocSet& o) {
+    const size_t n = std::min(w_.size(), o.w_.size());
+    for (size_t i = 0; i < n; ++i) w_[i] &= ~o.w_[i];
+    return *this;
+}
+std::vector<DocumentId> DocSet::to_ids() const {
+    std::vector<DocumentId> ids;
+    for (size_t i = 0; i < w_.size(); ++i) {
+        uint64_t w = w_[i];
+        while (w) {
+            ids.push_back((DocumentId)(i * 64 + (size_t)__builtin_ctzll(w)));
+            w &= w - 1;
+        }
+    }
+    return ids;
+}
+
+// ---- DistributionShift (src/vector/mod.rs:395-433) ----------------------------------------
+
+std::optional<DistributionShift> DistributionShift::create(float mean, float sigma) {
+    if (sigma <= 0.0f) return std::nullopt;
+    return DistributionShift{mean, sigma};
+}
+
+float DistributionShift::shift(float score) const {
+    // every operation in f32 and in the reference's order; no fused multiply-add
+    const volatile float target_mean = 0.5f;
+    const volatile float target_sigma = 0.4f;
+    const volatile float factor = target_sigma / current_sigma;
+    const volatile float scaled_mean = factor * current_mean;
+    const volatile float offset = target_mean - scaled_mean;
+    const volatile float scaled = factor * score;
+    float out = scaled + offset;
+    // clamp the final score in the ]0, 1] interval
+    if (out <= 0.0f) out = std::numeric_limits<float>::epsilon();
+    if (out > 1.0f) out = 1.0f;
+    return out;
+}
+
+// ---- score details (src/score_details.rs) ------------------------------------------------------
+
+Rank Rank::merge(Rank outer, Rank inner) {
+    outer.rank = outer.rank ? outer.rank - 1 : 0;  // saturating_sub(1)
+    outer.rank *= inner.max_rank;
+    outer.max_rank *= inner.max_rank;
+    outer.rank += inner.rank;
+    return outer;
+}
+
+double Rank::global_score(const std::vector<Rank>& details) {
+    Rank rank{1, 1};
+    for (const Rank& inner : details) rank = merge(rank, inner);
+    return rank.local_score();
+}
+
+std::optional<int> Sort::partial_cmp(const Sort& other) const {
+    if (field_name != other.field_name) return std::nullopt;
+    if (ascending != other.ascending) return std::nullopt;
+    const SortValue &l = value, &r = other.value;
+    if (l.kind == SortValue::Null && r.kind == SortValue::Null) return 0;
+    if (l.kind == SortValue::Null) return -1;
+    if (r.kind == SortValue::Null) return 1;
+    // numbers are always before strings
+    if (l.kind == SortValue::Number && r.kind == SortValue::String) return 1;
+    if (l.kind == SortValue::String && r.kind == SortValue::Number) return -1;
+    if (l.kind == SortValue::Number && r.kind == SortValue::Number) {
+        if (std::isnan(l.number) || std::isnan(r.number)) return std::nullopt;
+        const int order = l.number < r.number ? -1 : l.number > r.number ? 1 : 0;
+        // when ascending, smaller is better
+        return ascending ? -order : order;
+    }
+    if (l.kind == SortValue::String && r.kind == SortValue::String) {
+        const int c = l.string.compare(r.string);
+        const int order = c < 0 ? -1 : c > 0 ? 1 : 0;
+        return ascending ? -order : order;
+    }
+    return std::nullopt;
+}
+
+ScoreDetails ScoreDetails::vector(std::optional<float> similarity) {
+    ScoreDetails d;
+    d.kind = Vector;
+    d.similarity = similarity;
+    return d;
+}
+ScoreDetails ScoreDetails::ranked(Kind kind, uint32_t value, uint32_t max_value) {
+    ScoreDetails d;
+    d.kind = kind;
+    d.value = value;
+    d.max_value = max_value;
+    return d;
+}
+ScoreDetails ScoreDetails::sorted(Sort sort) {
+    ScoreDetails d;
+    d.kind = SortKind;
+    d.sort = std::move(sort);
+    return d;
+}
+
+std::optional<Rank> ScoreDetails::rank() const {
+    switch (kind) {
+        case Words:      // score_details.rs:183-185
+        case Exactness:  // :203-206
+        case Attribute:  // :269-271
+            return Rank{value + 1, max_value + 1};
+        case Typo:       // :247-252
+        case Proximity:  // :225-230
+        {
+            const uint32_t top = max_value + 1;
+            return Rank{top > value ? top - value : 0, top};
+        }
+        default:
+            return std::nullopt;
+    }
+}
+
+std::vector<ScoreValue> score_values(const std::vector<ScoreDetails>& details) {
+    // rank_or_value, then coalesce runs of ranks with Rank::merge (score_details.rs:59-89)
+    std::vector<ScoreValue> out;
+    std::optional<Rank> pending;
+    auto flush = [&]() {
+        if (pending) {
+            ScoreValue v;
+            v.score = pending->local_score();
+            out.push_back(v);
+            pending.reset();
+        }
+    };
+    for (const ScoreDetails& d : details) {
+        if (std::optional<Rank> r = d.rank()) {
+            pending = pending ? Rank::merge(*pending, *r) : *r;
+        } else if (d.kind == ScoreDetails::SortKind) {
+            flush();
+            ScoreValue v;
+            v.is_score = false;
+            v.sort = &d.sort;
+            out.push_back(v);
+        } else {
+            flush();
+            ScoreValue v;
+            v.score = d.similarity ? (double)*d.similarity : 0.0;
+            out.push_back(v);
+        }
+    }
+    flush();
+    return out;
+}
+
+double global_score(const std::vector<ScoreDetails>& details) {
+    for (const ScoreValue& v : score_values(details))
+        if (v.is_score) return v.score;
+    return 1.0;
+}
+
+namespace {
+std::string fmt_f64(double v) {
+    if (!std::isfinite(v)) return "null";  // serde_json renders non-finite floats as null
+    char buf[64];
+    auto res = std::to_chars(buf, buf + sizeof buf, v);
+    std::string s(buf, res.ptr);
+    if (s.find_first_of(".en") == std::string::npos) s += ".0";
+    return s;
+}
+std::string json_string(const std::string& s) {
+    std::string o = "\"";
+    for (unsigned char c : s) {
+        if (c == '"') o += "\\\"";
+        else if (c == '\\') o += "\\\\";
+        else if (c == '\n') o += "\\n";
+        else if (c == '\t') o += "\\t";
+        else if (c == '\r') o += "\\r";
+        else if (c < 0x20) {
+            char b[8];
+            snprintf(b, sizeof b, "\\u%04x", c);
+            o += b;
+        } else o += (char)c;
+    }
+    return o + "\"";
+}
+std::string sort_value_json(const SortValue& v) {
+    switch (v.kind) {
+        case SortValue::Number: return fmt_f64(v.number);
+        case SortValue::String: return json_string(v.string);
+        default: return "null";
+    }
+}
+}  // namespace
+
+std::string to_json_map(const std::vector<ScoreDetails>& details) {
+    // score_details.rs:91-171; serde_json is built with preserve_order, so keys
+    // keep insertion order, and a repeated key overwrites in place.
+    std::vector<std::pair<std::string, std::string>> entries;
+    auto put = [&](const std::string& key, const std::string& value) {
+        for (auto& e : entries)
+            if (e.first == key) {
+                e.second = value;
+                return;
+            }
+        entries.emplace_back(key, value);
+    };
+    int order = 0;
+    for (const ScoreDetails& d : details) {
+        const std::string o = std::to_string(order);
+        auto ranked = [&](const char* name, const char* a, const char* b) {
+            put(name, "{\"order\":" + o + ",\"" + a + "\":" + std::to_string(d.value) + ",\"" + b +
+                          "\":" + std::to_string(d.max_value) + ",\"score\":" +
+                          fmt_f64(d.rank()->local_score()) + "}");
+        };
+        switch (d.kind) {
+            case ScoreDetails::Words: ranked("words", "matchingWords", "maxMatchingWords"); break;
+            case ScoreDetails::Typo: ranked("typo", "typoCount", "maxTypoCount"); break;
+            case ScoreDetails::Proximity: ranked("proximity", "proximity", "maxProximity"); break;
+            case ScoreDetails::Attribute: ranked("attribute", "attribute", "maxAttribute"); break;
+            case ScoreDetails::Exactness: ranked("exactness", "exactWords", "maxExactWords"); break;
+            case ScoreDetails::SortKind:
+                put(d.sort.field_name + (d.sort.ascending ? ":asc" : ":desc"),
+                    "{\"order\":" + o + ",\"value\":" + sort_value_json(d.sort.value) + "}");
+                break;
+            case ScoreDetails::Vector:
+                put("vectorSort", "{\"order\":" + o + ",\"similarity\":" +
+                                      (d.similarity ? fmt_f64((double)*d.similarity) : "null") + "}");
+                break;
+        }
+        ++order;
+    }
+    std::string out = "{";
+    for (size_t i = 0; i < entries.size(); ++i) {
+        if (i) out += ",";
+        out += json_string(entries[i].first) + ":" + entries[i].second;
+    }
+    return out + "}";
+}
+
+// ---- bucket_sort (src/search/ranking/bucket_sort.rs:17-84) ------------------------------------------
+
+namespace {
+void recursive_sort(size_t current_rule, std::vector<ScoreDetails>& score,
+                    std::vector<std::unique_ptr<RankingRule>>& ranking_rule, uint64_t& limit,
+                    uint64_t& skip, std::vector<std::pair<DocumentId, std::vector<ScoreDetails>>>& output,
+                    DocSet& visited) {
+    while (std::optional<RankingRuleOutput> bucket = ranking_rule[current_rule]->next_bucket()) {
+        if (limit == 0) return;
+        DocSet& docids = bucket->candidates;
+        docids -= visited;
+        const uint64_t len = docids.len();
+        if (len == 0) continue;
+        if (skip > 0 && len < skip) {
+            visited |= docids;
+            skip -= len;
+            continue;
+        }
+        score.push_back(bucket->score);
+        if (current_rule == ranking_rule.size() - 1) {
+            visited |= docids;
+            const uint64_t docids_count = len;
+            uint64_t seen = 0, taken = 0;
+            for (DocumentId d : docids.to_ids()) {
+                if (seen++ < skip) continue;
+                if (taken++ >= limit) break;
+                output.emplace_back(d, score);
+            }
+            const uint64_t used = docids_count < skip ? 0 : docids_count - skip;
+            limit = limit > used ? limit - used : 0;  // saturating_sub
+            skip = docids_count < skip ? skip - docids_count : 0;
+            score.pop_back();
+        } else {
+            ranking_rule[current_rule + 1]->start_iteration(bucket->candidates);
+            recursive_sort(current_rule + 1, score, ranking_rule, limit, skip, output, visited);
+        }
+    }
+    if (!score.empty()) score.pop_back();  // Vec::pop on an empty vector is a no-op
+}
+}  // namespace
+
+BucketSortOutput bucket_sort(std::vector<std::unique_ptr<RankingRule>>& ranking_rules, uint64_t limit,
+                             uint64_t skip, DocSet candidates) {
+    BucketSortOutput out;
+    if (ranking_rules.empty()) {
+        out.docids = candidates.to_ids();
+        out.scores.assign(out.docids.size(), {});
+        out.candidates = std::move(candidates);
+        return out;
+    }
+    DocSet visited;
+    std::vector<ScoreDetails> score;
+    std::vector<std::pair<DocumentId, std::vector<ScoreDetails>>> output;
+    ranking_rules[0]->start_iteration(std::move(candidates));
+    recursive_sort(0, score, ranking_rules, limit, skip, output, visited);
+    for (auto& e : output) {
+        out.docids.push_back(e.first);
+        out.scores.push_back(std::move(e.second));
+    }
+    out.candidates = DocSet::from_ids(out.docids);  // only the returned documents (bucket_sort.rs:39)
+    return out;
+}
+
+// ---- GpuContext: the seam over the C ABI ----------------------------------------------------------------
+
+namespace {
+std::string last_error(vs_ctx* ctx) {
+    char buf[512];
+    vs_last_error(ctx, buf, sizeof buf);
+    return buf;
+}
+
+class GpuReader : public Reader {
+   public:
+    GpuReader(vs_ctx* ctx, vs_store* store) : ctx_(ctx), store_(store) {}
+    std::vector<std::pair<DocumentId, float>> nns_by_vector(const std::vector<float>& target, size_t count,
+                                                            const DocSet& candidates) override {
+        if (count > VS_MAX_K)
+            throw Error(Error::ArroyError, "limit " + std::to_string(count) + " exceeds VS_MAX_K");
+        std::vector<uint32_t> ids(count ? count : 1);
+        std::vector<float> dist(count ? count : 1);
+        uint32_t n = 0;
+        static const uint64_t none = 0;
+        const std::vector<uint64_t>& w = candidates.words();
+        // an empty candidate set is an empty mask, not "no filter"
+        const int32_t rc = vs_search(store_, target.data(), (uint32_t)target.size(), (uint32_t)count,
+                                     w.empty() ? &none : w.data(), w.size(), ids.data(), dist.data(), &n);
+        if (rc == VS_E_DIM_MISMATCH) {
+            uint32_t e = 0, r = 0;
+            vs_last_dim_mismatch(ctx_, &e, &r);
+            throw Error(Error::InvalidVectorDimensions,
+                        "Invalid vector dimensions: expected: `" + std::to_string(e) + "`, found: `" +
+                            std::to_string(r) + "`.",
+                        e, r);
+        }
+        if (rc != VS_OK) throw Error(Error::ArroyError, last_error(ctx_));
+        std::vector<std::pair<DocumentId, float>> out(n);
+        for (uint32_t i = 0; i < n; ++i) out[i] = {ids[i], dist[i]};
+        return out;
+    }
+
+   private:
+    vs_ctx* ctx_;
+    vs_store* store_;
+};
+}  // namespace
+
+uint8_t GpuContext::embedder_category_id(const std::string& name) {
+    auto it = ids_.find(name);
+    if (it == ids_.end()) throw Error(Error::InvalidEmbedder, "Invalid embedder `" + name + "`.");
+    return it->second;
+}
+
+std::unique_ptr<Reader> GpuContext::vector_reader(uint16_t index) {
+    vs_store* store = nullptr;
+    const int32_t rc = vs_store_open(ctx_, index, &store);
+    if (rc == VS_E_NO_STORE) return nullptr;  // MissingMetadata
+    if (rc != VS_OK) throw Error(Error::ArroyError, last_error(ctx_));
+    return std::unique_ptr<Reader>(new GpuReader(ctx_, store));
+}
+
+// ---- VectorSort (src/search/ranking/vector_sort.rs) ------------------------------------------------------
+
+VectorSort::VectorSort(Context& ctx, std::vector<float> target, DocSet vector_candidates, size_t limit,
+                       const std::string& embedder_name, std::optional<DistributionShift> distribution)
+    : ctx_(ctx),
+      target_(std::move(target)),
+      vector_candidates_(std::move(vector_candidates)),
+      limit_(limit),
+      distribution_shift_(distribution),
+      embedder_index_(ctx.embedder_category_id(embedder_name)) {}
+
+void VectorSort::fill_buffer(const DocSet& vector_candidates) {
+    const uint16_t writer_index = (uint16_t)((uint16_t)embedder_index_ << 8);
+    std::vector<std::unique_ptr<Reader>> readers;
+    for (uint32_t k = 0; k <= 0xFF; ++k) {
+        std::unique_ptr<Reader> reader = ctx_.vector_reader((uint16_t)(writer_index | k));
+        if (!reader) break;  // MissingMetadata ends the map_while
+        readers.push_back(std::move(reader));
+    }
+    std::vector<std::pair<DocumentId, float>> results;
+    for (auto& reader : readers) {
+        auto nns = reader->nns_by_vector(target_, limit_, vector_candidates);
+        results.insert(results.end(), nns.begin(), nns.end());
+    }
+    // The reference sorts by distance alone with an unstable sort, so the order
+    // of equal distances from different stores is unspecified there; here it is
+    // fixed as (distance, docid, store order), which a stable sort on
+    // (distance, docid) gives. NaN sorts last, as OrderedFloat does.
+    std::stable_sort(results.begin(), results.end(), [](const auto& a, const auto& b) {
+        const bool an = std::isnan(a.second), bn = std::isnan(b.second);
+        if (an != bn) return bn;
+        if (!an && a.second != b.second) return a.second < b.second;
+        return a.first < b.first;
+    });
+    cached_sorted_docids_ = std::move(results);
+    cursor_ = 0;
+}
+
+void VectorSort::start_iteration(DocSet candidates) {
+    candidates_ = std::move(candidates);
+    const DocSet vector_candidates = vector_candidates_ & candidates_;
+    fill_buffer(vector_candidates);
+}
+
+std::optional<RankingRuleOutput> VectorSort::next_bucket() {
+    for (;;) {  // the reference recurses after a refill
+        if (candidates_.is_empty()) return std::nullopt;
+        const DocSet vector_candidates = vector_candidates_ & candidates_;
+        if (vector_candidates.is_empty()) {
+            candidates_ = DocSet();
+            return RankingRuleOutput{ScoreDetails::vector(std::nullopt), candidates_};
+        }
+        while (cursor_ < cached_sorted_docids_.size()) {
+            const auto [docid, distance] = cached_sorted_docids_[cursor_++];
+            if (vector_candidates.contains(docid)) {
+                float score = 1.0f - distance;
+                if (distribution_shift_) score = distribution_shift_->shift(score);
+                candidates_.remove(docid);
+                return RankingRuleOutput{ScoreDetails::vector(score), DocSet::from_ids({docid})};
+            }
+        }
+        // the cache is exhausted: refill it and run again
+        fill_buffer(vector_candidates);
+        if (cached_sorted_docids_.empty()) {
+            // no document with a vector is left in the universe
+            candidates_ = DocSet();
+            return RankingRuleOutput{ScoreDetails::vector(std::nullopt), candidates_};
+        }
+    }
+}
+
+// ---- execute_vector_search (src/search/search.rs:98-135, ranking_rule.rs:74-132) ----------------------------
+
+SearchResult execute_vector_search(Context& ctx, const std::vector<float>& vector, DocSet universe,
+                                   uint64_t skip, uint64_t limit, const std::string& embedder_name,
+                                   std::optional<DistributionShift> distribution,
+                                   const ExtraRules& extra_rules) {
+    std::vector<std::unique_ptr<RankingRule>> ranking_rules;
+    DocSet vector_candidates = ctx.all_docids();
+    ranking_rules.emplace_back(new VectorSort(ctx, vector, std::move(vector_candidates),
+                                              (size_t)(skip + limit), embedder_name, distribution));
+    if (extra_rules)
+        for (auto& r : extra_rules()) ranking_rules.push_back(std::move(r));
+    BucketSortOutput out = bucket_sort(ranking_rules, limit, skip, std::move(universe));
+    SearchResult res;
+    res.candidates = std::move(out.candidates);
+    res.documents_ids = std::move(out.docids);
+    res.document_scores = std::move(out.scores);
+    return res;
+}
+
+// ---- hybrid (src/search/hybrid.rs) ------------------------------------------------------------------------------
+
+int compare_scores(const ScoreWithRatio& left, const ScoreWithRatio& right) {
+    const std::vector<ScoreValue> l = score_values(left.first), r = score_values(right.first);
+    const float left_ratio = left.second, right_ratio = right.second;
+    for (size_t i = 0;; ++i) {
+        const bool lh = i < l.size(), rh = i < r.size();
+        if (!lh && !rh) return 0;
+        if (!lh) return -1;
+        if (!rh) return 1;
+        if (l[i].is_score && r[i].is_score) {
+            const double lv = l[i].score * (double)left_ratio;
+            const double rv = r[i].score * (double)right_ratio;
+            if (std::fabs(lv - rv) <= std::numeric_limits<double>::epsilon()) continue;
+            return lv < rv ? -1 : 1;  // partial_cmp().unwrap(): scores are never NaN here
+        }
+        if (!l[i].is_score && !r[i].is_score) {
+            const std::optional<int> c = l[i].sort->partial_cmp(*r[i].sort);
+            if (!c) throw std::logic_error("compare_scores: incomparable sort values");  // unwrap()
+            if (*c == 0) continue;
+            return *c;
+        }
+        if (l[i].is_score) return l[i].score == 0.0 ? -1 : 1;
+        return r[i].score == 0.0 ? 1 : -1;
+    }
+}
+
+bool results_good_enough(const SearchResult& keyword_results, float semantic_ratio, uint64_t limit,
+                         uint64_t offset) {
+    // a result is good enough if its keyword score is > 0.9 with a semantic ratio of 0.5
+    const double GOOD_ENOUGH_SCORE = 0.45;
+    if ((uint64_t)keyword_results.document_scores.size() < limit + offset) return false;
+    for (const auto& score : keyword_results.document_scores) {
+        const double s = global_score(score);
+        if (s * (double)(1.0f - semantic_ratio) < GOOD_ENOUGH_SCORE) return false;
+    }
+    return true;
+}
+
+std::pair<SearchResult, uint32_t> merge(const SearchResult& vector_results, float vector_ratio,
+                                        const SearchResult& keyword_results, float keyword_ratio,
+                                        uint64_t from, uint64_t length) {
+    // itertools merge_by: take from the vector side while compare_scores(left, right).is_ge()
+    SearchResult out;
+    uint32_t semantic_hit_count = 0;
+    DocSet documents_seen;
+    size_t vi = 0, ki = 0;
+    const size_t vn = vector_results.documents_ids.size(), kn = keyword_results.documents_ids.size();
+    uint64_t skipped = 0;
+    while (vi < vn || ki < kn) {
+        bool take_vector;
+        if (vi < vn && ki < kn) {
+            take_vector = compare_scores({vector_results.document_scores[vi], vector_ratio},
+                                         {keyword_results.document_scores[ki], keyword_ratio}) >= 0;
+        } else {
+            take_vector = vi < vn;
+        }
+        const SearchResult& src = take_vector ? vector_results : keyword_results;
+        const size_t at = take_vector ? vi++ : ki++;
+        const DocumentId docid = src.documents_ids[at];
+        if (!documents_seen.insert(docid)) continue;  // remove documents we already saw
+        if (skipped < from) {                         // start skipping after the filter
+            ++skipped;
+            continue;
+        }
+        if ((uint64_t)out.documents_ids.size() >= length) break;  // take after skipping
+        if (take_vector) ++semantic_hit_count;
+        out.documents_ids.push_back(docid);
+        out.document_scores.push_back(src.document_scores[at]);
+    }
+    out.candidates = vector_results.candidates | keyword_results.candidates;
+    return {std::move(out), semantic_hit_count};
+}
+
+std::pair<SearchResult, std::optional<uint32_t>> execute_hybrid(const HybridInput& in,
+                                                                float semantic_ratio) {
+    SearchResult keyword_results = in.keyword_search();
+    // completely skip semantic search if the results of the keyword search are good enough
+    if (results_good_enough(keyword_results, semantic_ratio, in.limit, in.offset))
+        return {std::move(keyword_results), 0u};
+    // no vector search against placeholder search
+    if (!in.query) return {std::move(keyword_results), 0u};
+    // no embedder, no semantic search
+    if (!in.has_semantic) return {std::move(keyword_results), 0u};
+    std::vector<float> vector_query;
+    if (in.vector) {
+        vector_query = *in.vector;
+    } else {
+        std::optional<std::vector<float>> e = in.embed_one ? in.embed_one(*in.query) : std::nullopt;
+        if (!e) return {std::move(keyword_results), 0u};  // "Embedding failed": keyword results only
+        vector_query = std::move(*e);
+    }
+    SearchResult vector_results = in.vector_search(vector_query);
+    auto merged = merge(vector_results, semantic_ratio, keyword_results, 1.0f - semantic_ratio,
+                        in.offset, in.limit);
+    if ((uint64_t)merged.first.documents_ids.size() > in.limit)
+        throw std::logic_error("execute_hybrid: more results than the limit");  // assert!
+    return {std::move(merged.first), merged.second};
+}
+
+}  // namespace search_engine

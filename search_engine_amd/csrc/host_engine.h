@@ -1,0 +1,261 @@
+// Host side above the C ABI: a C++ mirror of the parts of the reference crate
+// that sit on the vector-search path, with the reference's names, argument
+// meaning and error behaviour. (The reference is Rust; no Rust toolchain exists
+// where this is built, so the host logic a maintainer would keep in Rust is
+// restated here in C++ and driven through the same C ABI the Rust crate would
+// bind.) Everything in this file is CPU control flow; distances come only from
+// vs_search through a `Reader`.
+//
+//   DistributionShift                 src/vector/mod.rs:317-330, 395-433
+//   ScoreDetails, Rank, ScoreValue    src/score_details.rs
+//   RankingRule, RankingRuleOutput    src/search/ranking/ranking_rule.rs:17-27
+//   VectorSort                        src/search/ranking/vector_sort.rs
+//   bucket_sort / recursive_sort      src/search/ranking/bucket_sort.rs:17-91
+//   Context (vector methods)          src/search/context.rs:28,59,60
+//   execute_vector_search             src/search/search.rs:98-135
+//   hybrid merge                      src/search/hybrid.rs
+#pragma once
+#include <stdint.h>
+
+#include <functional>
+#include <map>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+struct vs_ctx;
+struct vs_store;
+
+namespace search_engine {
+
+using DocumentId = uint32_t;  // src/lib.rs:79
+
+// ---- errors (src/error.rs) ---------------------------------------------------
+
+struct Error : std::runtime_error {
+    enum Kind {
+        InvalidEmbedder,          // UserError::InvalidEmbedder (context.rs:183-186)
+        InvalidVectorDimensions,  // UserError::InvalidVectorDimensions (error.rs:262-264)
+        ArroyError                // InternalError::ArroyError (error.rs:266-272)
+    };
+    Kind kind;
+    uint32_t expected = 0, found = 0;
+    Error(Kind k, const std::string& msg, uint32_t e = 0, uint32_t f = 0)
+        : std::runtime_error(msg), kind(k), expected(e), found(f) {}
+};
+
+// ---- docid sets ----------------------------------------------------------------
+
+// Dense bitmap with the handful of RoaringBitmap operations the path uses. Bit
+// (d & 63) of word d >> 6 — the layout vs_search takes as its candidate mask.
+class DocSet {
+   public:
+    DocSet() = default;
+    static DocSet from_ids(const std::vector<DocumentId>& ids);
+    static DocSet from_words(std::vector<uint64_t> words);
+    bool contains(DocumentId d) const;
+    bool insert(DocumentId d);  // true if newly inserted
+    bool remove(DocumentId d);
+    uint64_t len() const;
+    bool is_empty() const;
+    DocSet operator&(const DocSet& o) const;
+    DocSet operator|(const DocSet& o) const;
+    DocSet& operator|=(const DocSet& o);
+    DocSet& operator-=(const DocSet& o);
+    std::vector<DocumentId> to_ids() const;  // ascending
+    const std::vector<uint64_t>& words() const { return w_; }
+
+   private:
+    std::vector<uint64_t> w_;
+};
+
+// ---- DistributionShift -----------------------------------------------------------
+
+struct DistributionShift {
+    float current_mean;
+    float current_sigma;
+    // `None` if sigma <= 0 (vector/mod.rs:397-403)
+    static std::optional<DistributionShift> create(float mean, float sigma);
+    float shift(float score) const;
+};
+
+// ---- score details ------------------------------------------------------------------
+
+struct Rank {
+    uint32_t rank;
+    uint32_t max_rank;
+    double local_score() const { return (double)rank / (double)max_rank; }
+    static Rank merge(Rank outer, Rank inner);
+    static double global_score(const std::vector<Rank>& details);
+};
+
+// serde_json::Value as far as Sort compares it
+struct SortValue {
+    enum Kind { Null, Number, String, Other } kind = Null;
+    double number = 0.0;
+    std::string string;
+};
+
+struct Sort {
+    std::string field_name;
+    bool ascending = true;
+    SortValue value;
+    // -1 / 0 / +1, nullopt where the reference returns None
+    std::optional<int> partial_cmp(const Sort& other) const;
+};
+
+struct ScoreDetails {
+    enum Kind { Words, Typo, Proximity, Exactness, Attribute, SortKind, Vector } kind = Vector;
+    // Words{matching_words,max_matching_words}, Typo{typo_count,max_typo_count},
+    // Proximity{proximity,max_proximity}, Exactness{exact_words,max_exact_words},
+    // Attribute{attribute,max_attribute}
+    uint32_t value = 0, max_value = 0;
+    Sort sort;
+    std::optional<float> similarity;  // Vector
+
+    static ScoreDetails vector(std::optional<float> similarity);
+    static ScoreDetails ranked(Kind kind, uint32_t value, uint32_t max_value);
+    static ScoreDetails sorted(Sort sort);
+    std::optional<Rank> rank() const;
+};
+
+struct ScoreValue {
+    bool is_score = true;
+    double score = 0.0;
+    const Sort* sort = nullptr;
+};
+
+std::vector<ScoreValue> score_values(const std::vector<ScoreDetails>& details);
+double global_score(const std::vector<ScoreDetails>& details);
+// serde_json rendering of ScoreDetails::to_json_map, keys in insertion order
+std::string to_json_map(const std::vector<ScoreDetails>& details);
+
+// ---- ranking rules ----------------------------------------------------------------------
+
+struct RankingRuleOutput {
+    ScoreDetails score;
+    DocSet candidates;
+};
+
+struct RankingRule {
+    virtual ~RankingRule() = default;
+    virtual void start_iteration(DocSet candidates) = 0;
+    virtual std::optional<RankingRuleOutput> next_bucket() = 0;
+};
+
+struct BucketSortOutput {
+    DocSet candidates;
+    std::vector<DocumentId> docids;
+    std::vector<std::vector<ScoreDetails>> scores;
+};
+
+BucketSortOutput bucket_sort(std::vector<std::unique_ptr<RankingRule>>& ranking_rules, uint64_t limit,
+                             uint64_t skip, DocSet candidates);
+
+// ---- the data-access seam --------------------------------------------------------------------
+
+// arroy::Reader<Angular> as VectorSort uses it.
+struct Reader {
+    virtual ~Reader() = default;
+    // nns_by_vector(txn, target, count, None, Some(candidates)): (item, distance)
+    // ascending by (distance, item). Throws Error.
+    virtual std::vector<std::pair<DocumentId, float>> nns_by_vector(const std::vector<float>& target,
+                                                                    size_t count,
+                                                                    const DocSet& candidates) = 0;
+};
+
+// The methods of `trait Context` the vector path calls.
+struct Context {
+    virtual ~Context() = default;
+    virtual DocSet all_docids() = 0;                                         // context.rs:28
+    virtual uint8_t embedder_category_id(const std::string& name) = 0;       // context.rs:59
+    // nullptr plays arroy::Error::MissingMetadata ("store k does not exist")
+    virtual std::unique_ptr<Reader> vector_reader(uint16_t index) = 0;       // context.rs:60
+};
+
+// Context over libvs_amd.so: vector_reader = vs_store_open, nns_by_vector = vs_search.
+class GpuContext : public Context {
+   public:
+    GpuContext(vs_ctx* ctx, std::map<std::string, uint8_t> embedder_category_ids, DocSet documents_ids)
+        : ctx_(ctx), ids_(std::move(embedder_category_ids)), docs_(std::move(documents_ids)) {}
+    DocSet all_docids() override { return docs_; }
+    uint8_t embedder_category_id(const std::string& name) override;
+    std::unique_ptr<Reader> vector_reader(uint16_t index) override;
+
+   private:
+    vs_ctx* ctx_;
+    std::map<std::string, uint8_t> ids_;
+    DocSet docs_;
+};
+
+// ---- VectorSort -------------------------------------------------------------------------------------
+
+class VectorSort : public RankingRule {
+   public:
+    VectorSort(Context& ctx, std::vector<float> target, DocSet vector_candidates, size_t limit,
+               const std::string& embedder_name, std::optional<DistributionShift> distribution);
+    void start_iteration(DocSet candidates) override;
+    std::optional<RankingRuleOutput> next_bucket() override;
+
+   private:
+    void fill_buffer(const DocSet& vector_candidates);
+    Context& ctx_;
+    std::vector<float> target_;
+    DocSet candidates_;
+    DocSet vector_candidates_;
+    std::vector<std::pair<DocumentId, float>> cached_sorted_docids_;
+    size_t cursor_ = 0;
+    size_t limit_;
+    std::optional<DistributionShift> distribution_shift_;
+    uint8_t embedder_index_;
+};
+
+// ---- search ----------------------------------------------------------------------------------------------
+
+struct SearchResult {
+    DocSet candidates;
+    std::vector<DocumentId> documents_ids;
+    std::vector<std::vector<ScoreDetails>> document_scores;
+};
+
+// Rules that follow VectorSort (the index's criteria on the placeholder graph in
+// the reference, ranking_rule.rs:98-130); built by the caller.
+using ExtraRules = std::function<std::vector<std::unique_ptr<RankingRule>>()>;
+
+SearchResult execute_vector_search(Context& ctx, const std::vector<float>& vector, DocSet universe,
+                                   uint64_t skip, uint64_t limit, const std::string& embedder_name,
+                                   std::optional<DistributionShift> distribution,
+                                   const ExtraRules& extra_rules = nullptr);
+
+// ---- hybrid ------------------------------------------------------------------------------------------------
+
+using ScoreWithRatio = std::pair<std::vector<ScoreDetails>, float>;
+// -1 / 0 / +1 = Less / Equal / Greater (hybrid.rs:19-56)
+int compare_scores(const ScoreWithRatio& left, const ScoreWithRatio& right);
+bool results_good_enough(const SearchResult& keyword_results, float semantic_ratio, uint64_t limit,
+                         uint64_t offset);
+// ScoreWithRatioResult::merge (hybrid.rs:74-135): (merged, semantic_hit_count)
+std::pair<SearchResult, uint32_t> merge(const SearchResult& vector_results, float vector_ratio,
+                                        const SearchResult& keyword_results, float keyword_ratio,
+                                        uint64_t from, uint64_t length);
+
+struct HybridInput {
+    std::optional<std::string> query;
+    bool has_semantic = false;
+    std::optional<std::vector<float>> vector;
+    uint64_t offset = 0, limit = 20;
+    // search.execute() without / with the semantic part, both with offset 0 and
+    // limit = limit + offset (hybrid.rs:140-156, 186-190)
+    std::function<SearchResult()> keyword_search;
+    std::function<SearchResult(const std::vector<float>&)> vector_search;
+    // embedder.embed_one(query): nullopt = embedding failed (hybrid.rs:176-183)
+    std::function<std::optional<std::vector<float>>(const std::string&)> embed_one;
+};
+// Search::execute_hybrid (hybrid.rs:138-199)
+std::pair<SearchResult, std::optional<uint32_t>> execute_hybrid(const HybridInput& in,
+                                                                float semantic_ratio);
+
+}  // namespace search_engine

@@ -1,0 +1,105 @@
+"""One logical store sharded over the ranks of a torch.distributed job.
+
+Documents are split into contiguous docid ranges, one per rank (one process per
+GPU), boundaries on multiples of 64 so that a dense candidate mask slices by
+word offset. A batch of queries is searched on every shard; ONE all-gather then
+moves the shard-local top-k keys (k * 8 bytes per query and rank) and one launch
+merges them. The merge is associative, so the result is identical to searching
+one store that holds everything.
+
+The reference has no counterpart (it is a single-process library); this is the
+multi-GPU form of VectorSort::fill_buffer's per-store loop
+(src/search/ranking/vector_sort.rs:73-78): shards play the role of stores, and
+the (distance, docid) order of the merged list is the one arroy returns.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_range(rank, world, n_docs, align=64):
+    """(first_docid, count) of `rank`'s shard; every boundary is a multiple of `align`."""
+    per = -(-n_docs // world)
+    per = -(-per // align) * align
+    first = min(rank * per, n_docs)
+    return first, max(0, min(n_docs, first + per) - first)
+
+
+# ---- the 64-bit sort key: (orderable(distance) << 32) | docid -------------------------------------
+# Host restatement of the device key so that CPU code (tests, tools) can build and
+# read key lists; the GPU path never calls these.
+
+KEY_NONE = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def pack_keys(distances, docids):
+    d = np.ascontiguousarray(distances, np.float32) + np.float32(0.0)  # -0.0 -> +0.0
+    u = d.view(np.uint32).astype(np.uint64)
+    neg = (u >> np.uint64(31)) == 1
+    o = np.where(neg, (~u) & np.uint64(0xFFFFFFFF), u | np.uint64(0x80000000))
+    o = np.where(np.isnan(d), np.uint64(0xFFC00000), o)
+    return (o << np.uint64(32)) | np.ascontiguousarray(docids, np.uint32).astype(np.uint64)
+
+
+def unpack_keys(keys):
+    keys = np.ascontiguousarray(keys).view(np.uint64)
+    keys = keys[keys != KEY_NONE]
+    o = (keys >> np.uint64(32)).astype(np.uint32)
+    u = np.where(o & np.uint32(0x80000000), o & np.uint32(0x7FFFFFFF), ~o)
+    return (keys & np.uint64(0xFFFFFFFF)).astype(np.uint32), u.astype(np.uint32).view(np.float32)
+
+
+class ShardedSearch:
+    """Batch search over a sharded store.
+
+    local_search(j, out_keys) must leave the shard-local ascending top-k keys of
+    the batch's j-th query in out_keys (an int64 tensor view of k entries, padded
+    with KEY_NONE); merge(gathered, world, n_queries, k) turns the all-gathered
+    keys [world][n_queries][k] into (ids, distances, counts). On the GPU those are
+    vs_search_device and vs_merge_topk_batch_device; tests inject CPU stand-ins to
+    exercise the sharding and the collective under gloo.
+    """
+
+    def __init__(self, local_search, merge, k, batch, device, group=None):
+        self.local_search = local_search
+        self.merge = merge
+        self.k = k
+        self.batch = batch
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.keys = torch.empty(batch * k, dtype=torch.int64, device=device)
+        self.gathered = (torch.empty(self.world * batch * k, dtype=torch.int64, device=device)
+                         if self.world > 1 else self.keys)
+
+    def run(self, n_queries=None):
+        """Searches queries 0..n_queries-1 of the current batch (default: a full batch)."""
+        n = self.batch if n_queries is None else n_queries
+        for j in range(n):
+            self.local_search(j, self.keys[j * self.k:(j + 1) * self.k])
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.gathered, self.keys, group=self.group)
+        return self.merge(self.gathered, self.world, n, self.k)
+
+
+def gpu_sharded_search(ctx, store, k, batch, device, query_ptr, mask_ptr, stream, group=None):
+    """ShardedSearch over libvs_amd.so. query_ptr(j) -> device address of the j-th query of the
+    current batch; mask_ptr -> device address of the shard-aligned candidate words (0 = none)."""
+    from . import abi
+    ws = torch.empty(store.workspace_bytes(k), dtype=torch.uint8, device=device)
+    out_ids = torch.empty(batch * k, dtype=torch.int32, device=device)
+    out_dist = torch.empty(batch * k, dtype=torch.float32, device=device)
+    out_n = torch.empty(batch, dtype=torch.int32, device=device)
+    dim = store.dim
+
+    def local_search(j, out_keys):
+        store.search_device(query_ptr(j), dim, k, mask_ptr(), ws.data_ptr(), out_keys.data_ptr(), stream())
+
+    def merge(gathered, world, n_queries, kk):
+        ctx.merge_topk_batch_device(gathered.data_ptr(), world, batch * kk, n_queries, kk, kk,
+                                    abi.VS_ANGULAR, out_ids.data_ptr(), out_dist.data_ptr(),
+                                    out_n.data_ptr(), stream())
+        return out_ids, out_dist, out_n
+
+    s = ShardedSearch(local_search, merge, k, batch, device, group)
+    s.workspace = ws  # keep alive
+    return s

@@ -1,0 +1,51 @@
+"""The shared library loads and exports every entry point include/vs_abi.h declares
+(no compute calls: this runs without a GPU)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_entry_points():
+    text = open(os.path.join(ROOT, "include", "vs_abi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\bint32_t\s+(vs_\w+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_surface():
+    names = declared_entry_points()
+    assert len(names) >= 28
+    for must in ("vs_init", "vs_store_create", "vs_store_open", "vs_store_upload", "vs_store_seal",
+                 "vs_search", "vs_search_roaring", "vs_search_batch", "vs_search_device",
+                 "vs_merge_topk_device", "vs_roaring_to_mask", "vs_cbo_roaring_to_mask"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from search_engine_amd import abi
+    raw = ctypes.CDLL(abi.LIB_PATH)
+    for name in declared_entry_points():
+        assert hasattr(raw, name), f"libvs_amd.so does not export {name}"
+        assert name in abi.SIGNATURES, f"abi.py has no binding for {name}"
+    assert sorted(abi.SIGNATURES) == declared_entry_points()
+
+
+def test_no_cpu_fallback_without_a_device():
+    """Without a usable GPU the library refuses to start instead of computing on the CPU."""
+    import torch
+    from search_engine_amd import abi
+    if torch.cuda.is_available():
+        abi.Context(0).close()
+        return
+    try:
+        abi.Context(0)
+    except abi.VsError as e:
+        assert e.code == abi.VS_E_DEVICE
+    else:
+        raise AssertionError("vs_init succeeded without a GPU")
+
+
+def test_host_binding_imports():
+    from search_engine_amd import _host
+    assert _host.distribution_shift(0.85, 0.1, 1.0) == 1.0

@@ -1,0 +1,109 @@
+"""End-to-end plumbing on the GPU: the C++ host mirror (VectorSort -> bucket_sort ->
+hybrid merge) driving libvs_amd.so through GpuContext, against the pure-Python
+restatement of the reference's host logic fed by the CPU oracle. This is the
+10k x 384 "plumbing" configuration: user-provided vectors, cosine top-10 with a
+facet filter, several vectors per document spread over stores (embedder << 8) | k."""
+import numpy as np
+import pytest
+
+from conftest import facet_mask, synthetic_vectors
+from oracle import host as ref
+from oracle import scan as oracle
+
+pytestmark = pytest.mark.gpu
+
+CATEGORY = 2  # embedder_category_id of "default" in this test
+
+
+def build_world(ctx, n_docs, dim, n_stores, seed, index_base):
+    """Docs own 1..n_stores vectors; the j-th vector of a doc lives in store j (packed stores,
+    src/update/index_documents/typed_chunk.rs:597-607). Returns GPU stores and CPU readers."""
+    rng = np.random.default_rng(seed)
+    counts = rng.integers(1, n_stores + 1, n_docs)
+    stores, readers = [], []
+    for k in range(n_stores):
+        docids = np.nonzero(counts > k)[0].astype(np.uint32)
+        vectors = synthetic_vectors(docids.size, dim, seed * 10 + k)
+        s = ctx.create_store(index_base | k, dim, n_docs)
+        s.upload(docids, vectors)
+        s.seal()
+        stores.append(s)
+
+        def nns(target, count, cand, docids=docids, vectors=vectors):
+            mask = oracle.bool_to_mask(np.isin(np.arange(n_docs), list(cand)))
+            ids, dist = oracle.nns_by_vector(vectors, np.asarray(target, np.float32), count,
+                                             docids=docids, mask=mask)
+            return list(zip(ids.tolist(), dist.tolist()))
+        readers.append(nns)
+    return stores, readers
+
+
+def test_vector_search_plumbing_10k_384(gpu_ctx):
+    from search_engine_amd import _host
+    n_docs, dim, n_stores = 10_000, 384, 3
+    stores, readers = build_world(gpu_ctx, n_docs, dim, n_stores, 5, CATEGORY << 8)
+    try:
+        all_docids = list(range(n_docs))
+        ctx = _host.GpuContext(gpu_ctx.handle.value, {"default": CATEGORY}, oracle.bool_to_mask(np.ones(n_docs, bool)))
+        universe_mask = facet_mask(n_docs, 10)
+        universe = np.nonzero(oracle.mask_to_bool(universe_mask, n_docs))[0].tolist()
+        for qi in range(3):
+            q = synthetic_vectors(1, dim, 900 + qi)[0].tolist()
+            for skip, limit, dist in ((0, 10, None), (5, 10, (0.5, 0.2)), (0, 20, None)):
+                got = _host.execute_vector_search(ctx, q, universe_mask, skip, limit, "default", dist)
+                want = ref.execute_vector_search(readers, all_docids, q, universe, skip, limit, dist)
+                assert got["documents_ids"] == want["documents_ids"]
+                assert len(got["documents_ids"]) == limit
+                assert set(got["documents_ids"]) <= set(universe)
+                for gs, ws in zip(got["document_scores"], want["document_scores"]):
+                    # similarity = shift(1 - d): |error| <= |factor| * (1e-5 d + 1e-6); factor <= 2 here
+                    assert gs[0]["similarity"] == pytest.approx(ws[0]["similarity"], abs=1.2e-5)
+        # unknown embedder -> InvalidEmbedder; wrong dimension -> InvalidVectorDimensions{expected, found}
+        with pytest.raises(_host.HostError) as e:
+            _host.execute_vector_search(ctx, q, universe_mask, 0, 10, "nope", None)
+        assert e.value.args[1] == "InvalidEmbedder"
+        with pytest.raises(_host.HostError) as e:
+            _host.execute_vector_search(ctx, q[:100], universe_mask, 0, 10, "default", None)
+        assert e.value.args[1:] == ("InvalidVectorDimensions", dim, 100)
+    finally:
+        for s in stores:
+            s.destroy()
+
+
+def test_hybrid_plumbing(gpu_ctx):
+    """semanticRatio 0.5 with a stubbed keyword list: the vector half comes from the GPU."""
+    from search_engine_amd import _host
+    n_docs, dim = 4000, 64
+    stores, readers = build_world(gpu_ctx, n_docs, dim, 1, 8, (CATEGORY + 1) << 8)
+    try:
+        all_docids = list(range(n_docs))
+        ctx = _host.GpuContext(gpu_ctx.handle.value, {"default": CATEGORY + 1},
+                               oracle.bool_to_mask(np.ones(n_docs, bool)))
+        for pass_percent in (1, 10, 50):
+            universe_mask = facet_mask(n_docs, pass_percent)
+            universe = np.nonzero(oracle.mask_to_bool(universe_mask, n_docs))[0].tolist()
+            q = synthetic_vectors(1, dim, 77)[0].tolist()
+            limit, offset = 10, 2
+            # keyword side: 8 documents of the universe with middling scores
+            kw_ids = universe[:8]
+            keyword = {"documents_ids": kw_ids, "candidates": kw_ids,
+                       "document_scores": [[{"kind": "words", "value": 2, "max": 3},
+                                            {"kind": "typo", "value": i % 3, "max": 2}] for i in range(8)]}
+            dist = (0.5, 0.15)
+
+            def gpu_vector_search(v):
+                return _host.execute_vector_search(ctx, list(v), universe_mask, 0, limit + offset, "default", dist)
+
+            def cpu_vector_search(v):
+                return ref.execute_vector_search(readers, all_docids, list(v), universe, 0, limit + offset, dist)
+
+            got, got_n = _host.execute_hybrid("query", True, q, offset, limit, lambda: keyword,
+                                              gpu_vector_search, None, 0.5)
+            want, want_n = ref.execute_hybrid("query", True, q, offset, limit, lambda: keyword,
+                                              cpu_vector_search, None, 0.5)
+            assert got["documents_ids"] == want["documents_ids"] and got_n == want_n
+            assert got["candidates"] == want["candidates"]
+            assert len(got["documents_ids"]) <= limit
+    finally:
+        for s in stores:
+            s.destroy()

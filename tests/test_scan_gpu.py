@@ -63,6 +63,28 @@ def test_appendix_b_known_answers(gpu_ctx):
     assert ids.tolist() == [1, 2]
 
 
+def test_scan_small_golden_fixture(gpu_ctx):
+    """tests/golden/scan_small.json: ids exactly as committed, distances against its float64 values."""
+    import json
+    import os
+    from helpers import tol
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scan_small.json")) as f:
+        g = json.load(f)
+    vectors = np.array(g["vectors"], np.float32)
+    q = np.array(g["query"], np.float32)
+    d64 = np.array(g["distances_f64"])
+    mask = oracle.bool_to_mask(np.isin(np.arange(vectors.shape[0]), g["candidates"]))
+    store = make_store(gpu_ctx, vectors)
+    try:
+        ids, dist = store.search(q, 10, mask)
+        assert ids.tolist() == g["top10_filtered"]
+        assert np.all(np.abs(dist - d64[ids]) <= tol(d64[ids]))
+        ids, dist = store.search(q, 10, None)
+        assert ids.tolist() == g["top10_unfiltered"] and dist[0] == 0.0  # the zero-norm row
+    finally:
+        store.destroy()
+
+
 @pytest.mark.parametrize("pass_percent", [None, 100, 50, 10, 1])
 def test_parity_768_filtered(gpu_ctx, pass_percent):
     n, dim, k = 40000, 768, 10
@@ -86,6 +108,26 @@ def test_parity_dimensions(gpu_ctx, dim):
     vectors = synthetic_vectors(n, dim, 7 + dim)
     q = synthetic_vectors(1, dim, 1000 + dim)[0]
     run_case(gpu_ctx, vectors, q, 10, mask=facet_mask(n, 50))
+
+
+@pytest.mark.parametrize("dim", [1, 7, 8, 9, 384, 768, 1536, 4096])
+def test_parity_bf16_rows(gpu_ctx, dim):
+    """bf16 stores have no counterpart in the reference: rows are rounded to bf16 (nearest
+    even) at upload, the query stays f32, norms come from the rounded rows. The oracle gets
+    the same rounded rows."""
+    from search_engine_amd import abi
+    n = 4000
+    vectors = synthetic_vectors(n, dim, 300 + dim)
+    rounded = oracle.bf16_round(vectors)
+    q = synthetic_vectors(1, dim, 400 + dim)[0]
+    mask = facet_mask(n, 50)
+    store = make_store(gpu_ctx, vectors, dtype=abi.VS_BF16)
+    try:
+        assert store.row_bytes == -(-dim // 8) * 16
+        np.testing.assert_array_equal(store.item_vector(17), rounded[17])
+        run_case(gpu_ctx, rounded, q, 10, mask=mask, store=store)
+    finally:
+        store.destroy()
 
 
 @pytest.mark.parametrize("k", [1, 2, 10, 63, 64, 65, 100, 128, 129, 1000, 1024])
