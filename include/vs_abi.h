@@ -164,7 +164,9 @@ int32_t vs_search_batch(vs_store* s, const float* queries, uint32_t n_q, uint32_
 int32_t vs_search_workspace_bytes(vs_store* s, uint32_t k, uint64_t* bytes);
 
 /* Enqueues one query on `hip_stream` and returns immediately.
- *   d_query:      `dim` f32 (or dim/64 u64 words for VS_BIN1 stores) in device memory
+ *   d_query:      `dim` f32 in device memory; for VS_BIN1 stores the packed query
+ *                 bits instead (bit i of the query in word i/64 at position i%64),
+ *                 vs_store_row_bytes bytes, zero padded
  *   d_mask_words: candidate words ALIGNED TO THE STORE: word j covers docids
  *                 docid_base + 64 j .. ; capacity/64 words; NULL = every item
  *   d_workspace:  vs_search_workspace_bytes bytes, private to this call until

@@ -127,24 +127,25 @@ __device__ __forceinline__ uint64_t wave_shift_up_u64(uint64_t v, uint64_t fill)
     return ((uint64_t)hi << 32) | lo;
 }
 
-// The k smallest keys one wave has seen, ascending. For k <= 64 the list lives in
-// a register pair (lane i holds the i-th smallest) and an insert is a compare, a
-// ballot and one cross-lane shift; larger k use the LDS list above. `tau` is the
-// k-th smallest so far (KEY_NONE while fewer than k keys are held): only keys
-// below it may be inserted.
+// The k smallest keys one wave has seen, ascending. For k <= 128 the list lives in
+// two register pairs (lane i holds the i-th and the (64+i)-th smallest) and an
+// insert is two compares, two ballots and a cross-lane shift; larger k use the
+// LDS list above. `tau` is the k-th smallest so far (KEY_NONE while fewer than k
+// keys are held): only keys below it may be inserted.
 struct WaveTopK {
+    static constexpr int REG_K = 128;
     volatile uint64_t* lds;  // k entries owned by this wave
     int k, lane;
     bool in_regs;
-    uint64_t mine;
+    uint64_t lo, hi;  // entries lane and 64 + lane
     uint64_t tau;
 
     __device__ __forceinline__ void init(volatile uint64_t* lds_, int k_, int lane_) {
         lds = lds_;
         k = k_;
         lane = lane_;
-        in_regs = k_ <= 64;
-        mine = KEY_NONE;
+        in_regs = k_ <= REG_K;
+        lo = hi = KEY_NONE;
         tau = KEY_NONE;
         if (!in_regs) {
             for (int i = lane; i < k; i += 64) lds[i] = KEY_NONE;
@@ -154,11 +155,15 @@ struct WaveTopK {
     // `key` is wave-uniform and < tau
     __device__ __forceinline__ void insert(uint64_t key) {
         if (in_regs) {
-            const int pos = __popcll(__ballot(mine < key));
-            const uint64_t up = wave_shift_up_u64(mine, KEY_NONE);
-            mine = lane < pos ? mine : (lane == pos ? key : up);
-            if (lane >= k) mine = KEY_NONE;
-            tau = readlane_u64(mine, k - 1);
+            const int pos = __popcll(__ballot(lo < key)) + __popcll(__ballot(hi < key));
+            const uint64_t carry = readlane_u64(lo, 63);
+            const uint64_t up_lo = wave_shift_up_u64(lo, KEY_NONE);
+            const uint64_t up_hi = wave_shift_up_u64(hi, carry);
+            lo = lane < pos ? lo : (lane == pos ? key : up_lo);
+            hi = lane + 64 < pos ? hi : (lane + 64 == pos ? key : up_hi);
+            if (lane >= k) lo = KEY_NONE;
+            if (lane + 64 >= k) hi = KEY_NONE;
+            tau = k <= 64 ? readlane_u64(lo, k - 1) : readlane_u64(hi, k - 65);
         } else {
             tau = list_insert(lds, k, key, lane);
         }
@@ -167,7 +172,8 @@ struct WaveTopK {
     // after a workgroup barrier)
     __device__ __forceinline__ void spill() {
         if (in_regs) {
-            if (lane < k) lds[lane] = mine;
+            if (lane < k) lds[lane] = lo;
+            if (lane + 64 < k) lds[lane + 64] = hi;
             wave_lds_fence();
         }
     }
@@ -179,11 +185,12 @@ struct WaveTopK {
             insert(key);
         }
     }
-    // i-th smallest for i = base + lane, valid for i < k
+    // i-th smallest for i = base + lane (base a multiple of 64), KEY_NONE for i >= k
     __device__ __forceinline__ uint64_t at_lane(int base) const {
-        if (in_regs) return mine;  // base == 0
         const int i = base + lane;
-        return i < k ? lds[i] : KEY_NONE;
+        if (i >= k) return KEY_NONE;
+        if (in_regs) return base == 0 ? lo : hi;
+        return lds[i];
     }
 };
 

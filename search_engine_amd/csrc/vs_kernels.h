@@ -42,6 +42,14 @@ hipError_t launch_scan_angular(const SlabView& s, const float* d_query, const ui
                                uint32_t* out_ids, float* out_dist, uint32_t* out_n,
                                const ScanTuning& t, hipStream_t stream);
 
+// Hamming scan of one query against a VS_BIN1 slab. `d_query` holds the packed
+// query bits, row_vecs * 16 bytes, zero padded. Outputs as launch_scan_angular;
+// a key's distance field is the integer Hamming distance.
+hipError_t launch_scan_hamming(const SlabView& s, const void* d_query, const uint64_t* cand,
+                               uint32_t k, uint64_t* partial, uint64_t* out_keys,
+                               uint32_t* out_ids, float* out_dist, uint32_t* out_n,
+                               const ScanTuning& t, hipStream_t stream);
+
 // ‖row‖₂ for slots [slot0, slot0 + n) of an angular slab, same summation order
 // as the scan uses for ⟨row, query⟩.
 hipError_t launch_norms(const SlabView& s, float* norms, uint64_t slot0, uint64_t n,

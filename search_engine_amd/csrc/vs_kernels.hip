@@ -26,7 +26,7 @@
 namespace vs {
 
 constexpr int WAVES = 4;               // waves per workgroup
-constexpr int QCAP = 64 + 16;          // row queue entries per wave: one mask word + leftovers
+constexpr int QCAP = 64 + 64;          // row queue entries per wave: one mask word + leftovers
 constexpr uint32_t NUM_CUS = 256;       // MI355X
 
 struct ScanArgs {
@@ -105,6 +105,81 @@ __device__ __forceinline__ float angular_distance(float pq, float pn, float qn) 
     return 0.0f;
 }
 
+// The skeleton both scan kernels share. The wave `w` of `W` owns the 64-slot mask
+// words w, w + W, w + 2W, ... Each lane fetches one of the next 64 of them (the
+// following batch is requested before this one is scored); words with a set bit
+// are then taken one at a time, their passing slots appended to the wave's queue
+// in LDS, and score(head, n) is called for GROUP queued slots at a time (the
+// last call may get fewer: n < GROUP).
+template <int GROUP, typename ScoreFn>
+__device__ __forceinline__ void scan_masked_slots(const uint64_t* __restrict__ present,
+                                                  const uint64_t* __restrict__ cand,
+                                                  uint64_t n_slots, uint32_t w, uint32_t W, int lane,
+                                                  volatile uint32_t* queue, ScoreFn&& score) {
+    static_assert(GROUP <= QCAP - 64, "queue too small");
+    const uint64_t n_words = n_slots >> 6;
+    const uint64_t my_words = w < n_words ? (n_words - w + W - 1) / W : 0;
+    auto fetch_words = [&](uint64_t t0) -> uint64_t {
+        const uint64_t t = t0 + (uint64_t)lane;
+        uint64_t wd = 0;
+        if (t < my_words) {
+            const uint64_t wi = (uint64_t)w + t * W;
+            wd = present[wi];
+            if (cand) wd &= cand[wi];
+        }
+        return wd;
+    };
+    uint32_t qcount = 0;
+    uint64_t wd_next = fetch_words(0);
+    for (uint64_t t0 = 0; t0 < my_words; t0 += 64) {
+        const uint64_t wd = wd_next;
+        if (t0 + 64 < my_words) wd_next = fetch_words(t0 + 64);
+        uint64_t nz = __ballot(wd != 0);
+        while (nz) {
+            const int b = __builtin_ctzll(nz);
+            nz &= nz - 1;
+            const uint64_t word = readlane_u64(wd, b);
+            const uint32_t slot0 = (uint32_t)(((uint64_t)w + (t0 + (uint64_t)b) * W) << 6);
+            if ((word >> lane) & 1) queue[qcount + lanes_below(word)] = slot0 + (uint32_t)lane;
+            qcount += (uint32_t)__popcll(word);
+            wave_lds_fence();
+            if (qcount >= (uint32_t)GROUP) {
+                uint32_t head = 0;
+                do {
+                    score(head, (uint32_t)GROUP);
+                    head += GROUP;
+                } while (qcount - head >= (uint32_t)GROUP);
+                // keep the (< GROUP) leftovers at the front
+                const uint32_t rem = qcount - head;
+                uint32_t v = 0;
+                if ((uint32_t)lane < rem) v = queue[head + lane];
+                wave_lds_fence();
+                if ((uint32_t)lane < rem) queue[lane] = v;
+                wave_lds_fence();
+                qcount = rem;
+            }
+        }
+    }
+    if (qcount) score(0, qcount);
+}
+
+// Workgroup epilogue: wave 0 absorbs the other waves' lists and writes the
+// workgroup's k best, rank-major, to partial[rank * gridDim.x + blockIdx.x].
+__device__ __forceinline__ void finish_block(WaveTopK& top, unsigned char* smem, int k, uint32_t wib,
+                                             int lane, uint64_t* partial) {
+    top.spill();
+    __syncthreads();
+    if (wib == 0) {
+        for (int v = 1; v < WAVES; ++v)
+            top.absorb(reinterpret_cast<volatile uint64_t*>(smem) + (size_t)v * k);
+        for (int base = 0; base < k; base += 64) {
+            const int i = base + lane;
+            const uint64_t key = top.at_lane(base);
+            if (i < k) partial[(uint64_t)i * gridDim.x + blockIdx.x] = key;
+        }
+    }
+}
+
 template <int ELEM, int NCH, int U, bool NT>
 __global__ __launch_bounds__(WAVES * 64) void scan_angular_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -171,67 +246,97 @@ __global__ __launch_bounds__(WAVES * 64) void scan_angular_kernel(ScanArgs a) {
         }
     };
 
-    // The wave owns the 64-slot mask words w, w + W, w + 2W, ... Each lane fetches
-    // one of the next 64 of them (the following batch is requested before this
-    // one is scored); words with a set bit are then taken one at a time, their
-    // passing slots appended to the queue, and the queue is scored U rows at a time.
-    const uint64_t n_words = a.n_slots >> 6;
-    const uint64_t my_words = w < n_words ? (n_words - w + W - 1) / W : 0;
-    auto fetch_words = [&](uint64_t t0) -> uint64_t {
-        const uint64_t t = t0 + (uint64_t)lane;
-        uint64_t wd = 0;
-        if (t < my_words) {
-            const uint64_t wi = (uint64_t)w + t * W;
-            wd = a.present[wi];
-            if (a.cand) wd &= a.cand[wi];
-        }
-        return wd;
-    };
-    uint32_t qcount = 0;
-    uint64_t wd_next = fetch_words(0);
-    for (uint64_t t0 = 0; t0 < my_words; t0 += 64) {
-        const uint64_t wd = wd_next;
-        if (t0 + 64 < my_words) wd_next = fetch_words(t0 + 64);
-        uint64_t nz = __ballot(wd != 0);
-        while (nz) {
-            const int b = __builtin_ctzll(nz);
-            nz &= nz - 1;
-            const uint64_t word = readlane_u64(wd, b);
-            const uint32_t slot0 = (uint32_t)(((uint64_t)w + (t0 + (uint64_t)b) * W) << 6);
-            if ((word >> lane) & 1) queue[qcount + lanes_below(word)] = slot0 + (uint32_t)lane;
-            qcount += (uint32_t)__popcll(word);
-            wave_lds_fence();
-            if (qcount >= (uint32_t)U) {
-                uint32_t head = 0;
-                do {
-                    score_rows(head, U);
-                    head += U;
-                } while (qcount - head >= (uint32_t)U);
-                // keep the (< U) leftovers at the front
-                const uint32_t rem = qcount - head;
-                uint32_t v = 0;
-                if ((uint32_t)lane < rem) v = queue[head + lane];
-                wave_lds_fence();
-                if ((uint32_t)lane < rem) queue[lane] = v;
-                wave_lds_fence();
-                qcount = rem;
+    scan_masked_slots<U>(a.present, a.cand, a.n_slots, w, W, lane, queue, score_rows);
+    finish_block(top, smem, k, wib, lane, a.partial);
+}
+
+// ---- Hamming scan of binary-quantised rows ----------------------------------------------
+//
+// No counterpart in the reference (its only metric is Angular): distance =
+// popcount(row XOR query) over the row's bits, results ascending by (distance,
+// docid). Rows are short (1536 bits = 192 B), so a wave-per-row schedule would
+// waste most lanes; instead FOUR lanes share a row: each loads every fourth
+// 16-byte vector of it (a quad reads 64 contiguous bytes per instruction),
+// popcounts its share, and two DPP adds give the row's distance to all four.
+// One pass scores 16 rows per wave, U passes are in flight together.
+struct HammingArgs {
+    const u32x4* rows;
+    const uint64_t* present;
+    const uint64_t* cand;
+    const u32x4* query;  // row_vecs vectors, zero padded
+    uint64_t* partial;
+    uint64_t n_slots;
+    uint32_t row_vecs;
+    uint32_t docid_base;
+    uint32_t k;
+};
+
+template <int NI, int U, bool NT>
+__global__ __launch_bounds__(WAVES * 64) void scan_hamming_kernel(HammingArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int quad = lane >> 2, sub = lane & 3;
+    const uint32_t wib = uniform_u32(threadIdx.x >> 6);
+    const uint32_t W = gridDim.x * WAVES;
+    const uint32_t w = blockIdx.x * WAVES + wib;
+    const int k = (int)a.k;
+    volatile uint32_t* queue =
+        reinterpret_cast<volatile uint32_t*>(smem + (size_t)WAVES * k * 8) + (size_t)wib * QCAP;
+    WaveTopK top;
+    top.init(reinterpret_cast<volatile uint64_t*>(smem) + (size_t)wib * k, k, lane);
+
+    // this lane's share of the query: vectors sub, sub + 4, ...
+    u32x4 q[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const uint32_t p = (uint32_t)(i * 4 + sub);
+        q[i] = p < a.row_vecs ? a.query[p] : u32x4{0u, 0u, 0u, 0u};
+    }
+
+    auto score_rows = [&](uint32_t head, uint32_t nvalid) {
+        uint32_t slot[U];
+        bool valid[U];
+        u32x4 x[U][NI];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t r = (uint32_t)(u * 16 + quad);
+            valid[u] = r < nvalid;
+            slot[u] = queue[head + (valid[u] ? r : 0u)];
+            const u32x4* rp = a.rows + (uint64_t)slot[u] * a.row_vecs;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const uint32_t p = (uint32_t)(i * 4 + sub);
+                if (i < NI - 1 || p < a.row_vecs) {
+                    x[u][i] = load_vec<NT>(rp + p);
+                } else {
+                    x[u][i] = u32x4{0u, 0u, 0u, 0u};
+                }
             }
         }
-    }
-    if (qcount) score_rows(0, qcount);
-
-    // workgroup merge: wave 0 absorbs the other waves' lists
-    top.spill();
-    __syncthreads();
-    if (wib == 0) {
-        for (int v = 1; v < WAVES; ++v)
-            top.absorb(reinterpret_cast<volatile uint64_t*>(smem) + (size_t)v * k);
-        for (int base = 0; base < k; base += 64) {
-            const int i = base + lane;
-            const uint64_t key = top.at_lane(base);
-            if (i < k) a.partial[(uint64_t)i * gridDim.x + blockIdx.x] = key;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cnt += (uint32_t)__popc(x[u][i][j] ^ q[i][j]);
+            }
+            cnt += dpp_u32<0xB1, 0xF>(cnt);  // quad_perm [1,0,3,2]
+            cnt += dpp_u32<0x4E, 0xF>(cnt);  // quad_perm [2,3,0,1]
+            const uint64_t key = make_key(cnt, a.docid_base + slot[u]);
+            const bool live = valid[u] && sub == 0;
+            uint64_t m = __ballot(live && key < top.tau);
+            while (m) {
+                const int src = __builtin_ctzll(m);
+                top.insert(readlane_u64(key, src));
+                m &= m - 1;
+                m &= __ballot(live && key < top.tau);
+            }
         }
-    }
+    };
+
+    scan_masked_slots<16 * U>(a.present, a.cand, a.n_slots, w, W, lane, queue, score_rows);
+    finish_block(top, smem, k, wib, lane, a.partial);
 }
 
 // ---- merge of sorted key lists ------------------------------------------------
@@ -488,6 +593,48 @@ hipError_t launch_scan_angular(const SlabView& s, const float* d_query, const ui
         return hipErrorInvalidValue;
     if (e != hipSuccess) return e;
     return launch_merge(partial, blocks, 1, blocks, k, VS_ANGULAR, out_keys, out_ids, out_dist,
+                        out_n, stream);
+}
+
+template <int NI, int U>
+static hipError_t launch_hamming_t(const HammingArgs& a, uint32_t blocks, size_t lds,
+                                   const ScanTuning& t, hipStream_t stream) {
+    const dim3 grid(blocks), block(WAVES * 64);
+    if (t.nt)
+        hipLaunchKernelGGL((scan_hamming_kernel<NI, U, true>), grid, block, lds, stream, a);
+    else
+        hipLaunchKernelGGL((scan_hamming_kernel<NI, U, false>), grid, block, lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_hamming(const SlabView& s, const void* d_query, const uint64_t* cand,
+                               uint32_t k, uint64_t* partial, uint64_t* out_keys,
+                               uint32_t* out_ids, float* out_dist, uint32_t* out_n,
+                               const ScanTuning& t, hipStream_t stream) {
+    if (k == 0 || k > VS_MAX_K || (s.n_slots & 63) || s.n_slots == 0 || s.dtype != VS_BIN1)
+        return hipErrorInvalidValue;
+    HammingArgs a;
+    a.rows = reinterpret_cast<const u32x4*>(s.rows);
+    a.present = s.present;
+    a.cand = cand;
+    a.query = reinterpret_cast<const u32x4*>(d_query);
+    a.partial = partial;
+    a.n_slots = s.n_slots;
+    a.row_vecs = s.row_vecs;
+    a.docid_base = s.docid_base;
+    a.k = k;
+    const uint32_t blocks = scan_grid_blocks(s, t, cand != nullptr);
+    const size_t lds = (size_t)WAVES * k * 8 + (size_t)WAVES * QCAP * 4;
+    const uint32_t ni = (s.row_vecs + 3) / 4;
+    hipError_t e;
+    if (ni <= 1) e = launch_hamming_t<1, 4>(a, blocks, lds, t, stream);
+    else if (ni <= 2) e = launch_hamming_t<2, 4>(a, blocks, lds, t, stream);
+    else if (ni <= 3) e = launch_hamming_t<3, 4>(a, blocks, lds, t, stream);
+    else if (ni <= 4) e = launch_hamming_t<4, 2>(a, blocks, lds, t, stream);
+    else if (ni <= 8) e = launch_hamming_t<8, 2>(a, blocks, lds, t, stream);
+    else return hipErrorInvalidValue;
+    if (e != hipSuccess) return e;
+    return launch_merge(partial, blocks, 1, blocks, k, VS_HAMMING, out_keys, out_ids, out_dist,
                         out_n, stream);
 }
 

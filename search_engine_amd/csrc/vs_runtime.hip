@@ -42,7 +42,8 @@ int32_t fail(int32_t code, const char* fmt, ...) {
                         #expr, hipGetErrorString(e_));                                     \
     } while (0)
 
-constexpr uint32_t MAX_DIM_VECS = 16 * 64;  // row vectors the scan kernels are built for
+constexpr uint32_t MAX_DIM_VECS = 16 * 64;  // row vectors the angular scan kernels are built for
+constexpr uint32_t MAX_BIN_VECS = 32;       // and the Hamming scan (4096 bits)
 constexpr size_t STAGE_BYTES = 32u << 20;
 
 // Everything one in-flight host-buffer search needs; handed out by the pool so
@@ -194,8 +195,21 @@ int32_t begin_search(vs_store* s, const float* query, uint32_t dim, uint32_t k, 
                     dim);
     }
     if (k > VS_MAX_K) return fail(VS_E_INVALID_ARG, "k = %u exceeds VS_MAX_K = %u", k, VS_MAX_K);
-    if (s->metric != VS_ANGULAR || s->dtype == VS_BIN1)
-        return fail(VS_E_INVALID_ARG, "store %u is not an angular f32/bf16 store", s->index);
+    return VS_OK;
+}
+
+// One scan of a sealed store: angular for f32/bf16 rows, Hamming for bin1 rows.
+int32_t launch_scan(vs_store* s, const void* d_query, const uint64_t* d_cand, uint32_t k,
+                    uint64_t* d_partial, uint64_t* d_keys, uint32_t* d_ids, float* d_dist,
+                    uint32_t* d_n, hipStream_t stream) {
+    const vs::SlabView v = s->view();
+    const vs::ScanTuning& t = s->ctx->tuning;
+    if (s->metric == VS_HAMMING)
+        HIP_TRY(vs::launch_scan_hamming(v, d_query, d_cand, k, d_partial, d_keys, d_ids, d_dist, d_n,
+                                        t, stream));
+    else
+        HIP_TRY(vs::launch_scan_angular(v, static_cast<const float*>(d_query), d_cand, k, d_partial,
+                                        d_keys, d_ids, d_dist, d_n, t, stream));
     return VS_OK;
 }
 
@@ -207,11 +221,22 @@ int32_t run_and_fetch(vs_store* s, Workspace* ws, const float* h_query, uint32_t
     const vs::ScanTuning& t = s->ctx->tuning;
     if (int32_t rc = grow(&ws->d_partial, &ws->partial_bytes, (size_t)vs::scan_partial_bytes(v, k, t)))
         return rc;
-    float* hq = reinterpret_cast<float*>(ws->h_pinned);
-    memcpy(hq, h_query, (size_t)s->dim * 4);
-    HIP_TRY(hipMemcpyAsync(ws->d_query, hq, (size_t)s->dim * 4, hipMemcpyHostToDevice, ws->stream));
-    HIP_TRY(vs::launch_scan_angular(v, ws->d_query, d_cand, k, ws->d_partial, nullptr, ws->d_ids,
-                                    ws->d_dist, ws->d_n, t, ws->stream));
+    size_t query_bytes;
+    if (s->dtype == VS_BIN1) {
+        // the query is quantised like the rows: bit i = (q[i] > 0), zero padded to whole vectors
+        uint64_t* hq = reinterpret_cast<uint64_t*>(ws->h_pinned);
+        query_bytes = (size_t)s->row_vecs * 16;
+        memset(hq, 0, query_bytes);
+        for (uint32_t i = 0; i < s->dim; ++i)
+            if (h_query[i] > 0.0f) hq[i >> 6] |= 1ull << (i & 63);
+    } else {
+        query_bytes = (size_t)s->dim * 4;
+        memcpy(ws->h_pinned, h_query, query_bytes);
+    }
+    HIP_TRY(hipMemcpyAsync(ws->d_query, ws->h_pinned, query_bytes, hipMemcpyHostToDevice, ws->stream));
+    if (int32_t rc = launch_scan(s, ws->d_query, d_cand, k, ws->d_partial, nullptr, ws->d_ids,
+                                 ws->d_dist, ws->d_n, ws->stream))
+        return rc;
     unsigned char* hr = ws->h_pinned + QUERY_BYTES;
     // ids, distances and the count are contiguous on the device
     HIP_TRY(hipMemcpyAsync(hr, ws->d_ids, (size_t)VS_MAX_K * 8 + 4, hipMemcpyDeviceToHost, ws->stream));
@@ -327,9 +352,9 @@ extern "C" int32_t vs_store_create(vs_ctx* ctx, uint16_t store_index, uint32_t d
         return fail(VS_E_INVALID_ARG, "docid range [%u, %u + %llu) does not fit u32 docids", docid_base,
                     docid_base, (unsigned long long)capacity);
     const uint32_t row_vecs = vecs_for(dim, dtype);
-    if (row_vecs > MAX_DIM_VECS)
+    if (row_vecs > (dtype == VS_BIN1 ? MAX_BIN_VECS : MAX_DIM_VECS))
         return fail(VS_E_INVALID_ARG, "dimension %u too large (row of %u bytes, limit %u)", dim,
-                    row_vecs * 16, MAX_DIM_VECS * 16);
+                    row_vecs * 16, (dtype == VS_BIN1 ? MAX_BIN_VECS : MAX_DIM_VECS) * 16);
     {
         std::lock_guard<std::mutex> g(ctx->mu);
         if (ctx->stores.count(store_index))
@@ -654,12 +679,8 @@ extern "C" int32_t vs_search_device(vs_store* s, const void* d_query, uint32_t d
                     dim);
     }
     if (k == 0 || k > VS_MAX_K) return fail(VS_E_INVALID_ARG, "k = %u out of range", k);
-    if (s->metric != VS_ANGULAR || s->dtype == VS_BIN1)
-        return fail(VS_E_INVALID_ARG, "store %u is not an angular f32/bf16 store", s->index);
-    HIP_TRY(vs::launch_scan_angular(s->view(), static_cast<const float*>(d_query), d_mask_words, k,
-                                    static_cast<uint64_t*>(d_workspace), d_out_keys, nullptr, nullptr,
-                                    nullptr, s->ctx->tuning, static_cast<hipStream_t>(hip_stream)));
-    return VS_OK;
+    return launch_scan(s, d_query, d_mask_words, k, static_cast<uint64_t*>(d_workspace), d_out_keys,
+                       nullptr, nullptr, nullptr, static_cast<hipStream_t>(hip_stream));
 }
 
 extern "C" int32_t vs_merge_topk_device(vs_ctx* ctx, const uint64_t* d_keys, uint32_t n_lists,

@@ -81,7 +81,8 @@ class ShardedSearch:
         return self.merge(self.gathered, self.world, n, self.k)
 
 
-def gpu_sharded_search(ctx, store, k, batch, device, query_ptr, mask_ptr, stream, group=None):
+def gpu_sharded_search(ctx, store, k, batch, device, query_ptr, mask_ptr, stream, group=None,
+                       metric=0):
     """ShardedSearch over libvs_amd.so. query_ptr(j) -> device address of the j-th query of the
     current batch; mask_ptr -> device address of the shard-aligned candidate words (0 = none)."""
     from . import abi
@@ -96,7 +97,7 @@ def gpu_sharded_search(ctx, store, k, batch, device, query_ptr, mask_ptr, stream
 
     def merge(gathered, world, n_queries, kk):
         ctx.merge_topk_batch_device(gathered.data_ptr(), world, batch * kk, n_queries, kk, kk,
-                                    abi.VS_ANGULAR, out_ids.data_ptr(), out_dist.data_ptr(),
+                                    metric, out_ids.data_ptr(), out_dist.data_ptr(),
                                     out_n.data_ptr(), stream())
         return out_ids, out_dist, out_n
 

@@ -1,0 +1,113 @@
+"""GPU parity tests of the Hamming scan over binary-quantised stores. Integer work:
+distances and the (distance, docid) order must be bit-exact against the CPU oracle.
+Binary stores have no counterpart in the reference (one metric, Angular); the
+definition under test is the build's own: bit i = (x[i] > 0), distance = popcount of XOR."""
+import numpy as np
+import pytest
+
+from conftest import facet_mask, synthetic_vectors
+from oracle import scan as oracle
+
+pytestmark = pytest.mark.gpu
+
+_next_index = [0x4000]
+
+
+def make_bin_store(ctx, vectors, docids=None, docid_base=0):
+    from search_engine_amd import abi
+    n, dim = vectors.shape
+    if docids is None:
+        docids = np.arange(n, dtype=np.uint32) + docid_base
+    _next_index[0] += 1
+    store = ctx.create_store(_next_index[0], dim, int(docids.max()) - docid_base + 1, dtype=abi.VS_BIN1,
+                             metric=abi.VS_HAMMING, docid_base=docid_base)
+    store.upload(docids, vectors)
+    store.seal()
+    return store
+
+
+def check(store, vectors, q, k, mask=None, docids=None):
+    codes = oracle.binarize(vectors)
+    qc = oracle.binarize(q[None, :])[0]
+    ids, dist = store.search(q, k, mask)
+    o_ids, o_dist = oracle.hamming_topk(codes, qc, k, docids=docids, mask=mask)
+    assert ids.tolist() == o_ids.tolist()
+    assert dist.tolist() == o_dist.astype(np.float32).tolist()
+    return ids, dist
+
+
+@pytest.mark.parametrize("dim", [1, 64, 100, 128, 129, 768, 1024, 1536, 2048, 4096])
+def test_hamming_parity_dimensions(gpu_ctx, dim):
+    n = 5000
+    vectors = synthetic_vectors(n, dim, 500 + dim)
+    q = synthetic_vectors(1, dim, 600 + dim)[0]
+    store = make_bin_store(gpu_ctx, vectors)
+    try:
+        assert store.row_bytes == -(-dim // 128) * 16
+        check(store, vectors, q, 100, facet_mask(n, 50))
+        check(store, vectors, q, 10, None)
+        bits = store.item_vector(3)
+        np.testing.assert_array_equal(bits, (vectors[3] > 0).astype(np.float32))
+    finally:
+        store.destroy()
+
+
+@pytest.mark.parametrize("pass_percent", [None, 100, 50, 10, 1])
+@pytest.mark.parametrize("k", [1, 100, 128, 129, 1000])
+def test_hamming_parity_1536_filtered(gpu_ctx, pass_percent, k):
+    """Distances over 1536 bits collide constantly, so this is mostly a test of the docid tie-break."""
+    n, dim = 60000, 1536
+    vectors = synthetic_vectors(n, dim, 0xB175)
+    q = synthetic_vectors(1, dim, 43)[0]
+    mask = None if pass_percent is None else facet_mask(n, pass_percent)
+    store = make_bin_store(gpu_ctx, vectors)
+    try:
+        ids, dist = check(store, vectors, q, k, mask)
+        assert len(set(dist.tolist())) < ids.size or k == 1  # ties present
+    finally:
+        store.destroy()
+
+
+def test_hamming_sparse_docids_and_device_api(gpu_ctx):
+    import torch
+    from search_engine_amd import abi
+    dim, base, k = 256, 64 * 50, 20
+    rng = np.random.default_rng(4)
+    docids = np.sort(rng.choice(30000, 9000, replace=False)).astype(np.uint32) + base
+    vectors = synthetic_vectors(docids.size, dim, 71)
+    q = synthetic_vectors(1, dim, 72)[0]
+    mask = facet_mask(base + 30000, 50)
+    store = make_bin_store(gpu_ctx, vectors, docids, docid_base=base)
+    try:
+        ids, dist = check(store, vectors, q, k, mask, docids)
+        # device entry point: packed query bits, shard-aligned mask, keys out, then merge/decode
+        dev = torch.device("cuda:0")
+        qc = oracle.binarize(q[None, :])[0]
+        d_q = torch.from_numpy(qc.view(np.int64)).to(dev)
+        d_mask = torch.from_numpy(mask.view(np.int64)).to(dev)
+        ws = torch.empty(store.workspace_bytes(k), dtype=torch.uint8, device=dev)
+        keys = torch.empty(k, dtype=torch.int64, device=dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        store.search_device(d_q.data_ptr(), dim, k, d_mask.data_ptr() + 8 * (base // 64), ws.data_ptr(),
+                            keys.data_ptr(), stream)
+        o_ids = torch.empty(k, dtype=torch.int32, device=dev)
+        o_dist = torch.empty(k, dtype=torch.float32, device=dev)
+        o_n = torch.empty(1, dtype=torch.int32, device=dev)
+        gpu_ctx.merge_topk_device(keys.data_ptr(), 1, k, abi.VS_HAMMING, o_ids.data_ptr(), o_dist.data_ptr(),
+                                  o_n.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert o_ids.cpu().numpy().astype(np.uint32).tolist() == ids.tolist()
+        assert o_dist.cpu().numpy().tolist() == dist.tolist()
+        # a key is (distance << 32) | docid
+        kk = keys.cpu().numpy().view(np.uint64)
+        assert (kk >> np.uint64(32)).tolist() == dist.astype(np.uint64).tolist()
+    finally:
+        store.destroy()
+
+
+def test_metric_and_dtype_must_agree(gpu_ctx):
+    from search_engine_amd import abi
+    for dtype, metric in ((abi.VS_BIN1, abi.VS_ANGULAR), (abi.VS_F32, abi.VS_HAMMING)):
+        with pytest.raises(abi.VsError) as e:
+            gpu_ctx.create_store(0x4FFF, 64, 100, dtype=dtype, metric=metric)
+        assert e.value.code == abi.VS_E_INVALID_ARG

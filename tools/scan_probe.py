@@ -29,26 +29,36 @@ def main():
     dev = torch.device("cuda", 0)
     ctx = abi.Context(0)
     n = -(-args.docs // 64) * 64
-    dtype = abi.VS_F32 if args.dtype == "f32" else abi.VS_BF16
+    dtype = {"f32": abi.VS_F32, "bf16": abi.VS_BF16, "bin1": abi.VS_BIN1}[args.dtype]
     tdtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
-    store = ctx.create_store(0, args.dim, n, dtype=dtype)
+    binary = args.dtype == "bin1"
+    store = ctx.create_store(0, args.dim, n, dtype=dtype,
+                             metric=abi.VS_HAMMING if binary else abi.VS_ANGULAR)
     gen = torch.Generator(device=dev)
     gen.manual_seed(0xC0FFEE)
     stream = torch.cuda.current_stream().cuda_stream
     for lo in range(0, args.docs, 1 << 18):
         m = min(1 << 18, args.docs - lo)
-        rows = torch.randn(m, args.dim, generator=gen, device=dev).to(tdtype)
+        if binary:
+            assert args.dim % 128 == 0
+            rows = torch.randint(-2**63, 2**63 - 1, (m, args.dim // 64), generator=gen, device=dev,
+                                 dtype=torch.int64)
+        else:
+            rows = torch.randn(m, args.dim, generator=gen, device=dev).to(tdtype)
         store.upload_device(lo, rows.data_ptr(), m, stream)
         torch.cuda.synchronize()
     store.seal()
-    queries = torch.randn(64, args.dim, device=dev)
+    if binary:
+        queries = torch.randint(-2**63, 2**63 - 1, (64, args.dim // 64), device=dev, dtype=torch.int64)
+    else:
+        queries = torch.randn(64, args.dim, device=dev)
     keys = torch.empty(args.k, dtype=torch.int64, device=dev)
     variants = [tuple(int(x) for x in v.split(":")) for v in args.variants.split(",")]
     lut = torch.tensor([bin(v).count("1") for v in range(256)], dtype=torch.int64, device=dev)
     for p in [int(x) for x in args.pass_percents.split(",")]:
         mask = device_mask(0, n, p, dev)
         n_pass = int(lut[mask.view(torch.uint8).long()].sum().item())
-        algo = n_pass * (store.row_bytes + 4) + n // 8
+        algo = n_pass * (store.row_bytes + (0 if binary else 4)) + n // 8
         times = {v: [] for v in variants}
         ref = None
         for r in range(args.rounds + 1):
