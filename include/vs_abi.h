@@ -64,6 +64,10 @@ enum { VS_ANGULAR = 0, VS_HAMMING = 1 };
 #define VS_KEY_NONE 0xFFFFFFFFFFFFFFFFull
 /* Largest `k` any search accepts. */
 #define VS_MAX_K 1024u
+/* Largest `k` of the batched matrix-core path (vs_search_batch_device). */
+#define VS_BATCH_MAX_K 32u
+/* Queries one batched launch takes. */
+#define VS_BATCH_MAX_QUERIES 256u
 
 /* ---- context ------------------------------------------------------------ */
 
@@ -152,8 +156,10 @@ int32_t vs_search_roaring(vs_store* s, const float* query, uint32_t dim, uint32_
                           float* out_dist, uint32_t* out_n);
 
 /* `n_q` queries against one shared candidate mask. out_ids / out_dist hold
- * n_q * k entries (query i at offset i * k), out_n holds n_q counts. No
- * reference counterpart (the reference searches one vector per request). */
+ * n_q * k entries (query i at offset i * k), out_n holds n_q counts. On a
+ * VS_BF16 store with k <= VS_BATCH_MAX_K this runs the batched matrix-core scan
+ * (queries rounded to bf16); otherwise one scan per query. No reference
+ * counterpart (the reference searches one vector per request). */
 int32_t vs_search_batch(vs_store* s, const float* queries, uint32_t n_q, uint32_t dim,
                         uint32_t k, const uint64_t* mask_words, uint64_t n_mask_words,
                         uint32_t* out_ids, float* out_dist, uint32_t* out_n);
@@ -177,6 +183,16 @@ int32_t vs_search_workspace_bytes(vs_store* s, uint32_t k, uint64_t* bytes);
 int32_t vs_search_device(vs_store* s, const void* d_query, uint32_t dim, uint32_t k,
                          const uint64_t* d_mask_words, void* d_workspace, uint64_t* d_out_keys,
                          void* hip_stream);
+
+/* Batched form for VS_BF16 stores, on the matrix cores: `n_q` <= VS_BATCH_MAX_QUERIES
+ * queries (f32 [n_q][dim] in device memory; rounded to bf16 on the device, so the
+ * distances are those of the rounded queries) share ONE pass over the rows and one
+ * candidate mask. k <= VS_BATCH_MAX_K. d_out_keys receives n_q lists of k keys.
+ * No reference counterpart (the reference searches one vector per request). */
+int32_t vs_search_batch_workspace_bytes(vs_store* s, uint32_t k, uint64_t* bytes);
+int32_t vs_search_batch_device(vs_store* s, const float* d_queries, uint32_t n_q, uint32_t dim,
+                               uint32_t k, const uint64_t* d_mask_words, void* d_workspace,
+                               uint64_t* d_out_keys, void* hip_stream);
 
 /* Merges `n_lists` ascending key lists of `k` entries each (list i at
  * d_keys + i * k; e.g. the all-gathered shard results) into the global top-k

@@ -53,6 +53,8 @@ SIGNATURES = {
     "vs_search_batch": [_vp, _f32p, _u32, _u32, _u32, _u64p, _u64, _u32p, _f32p, _u32p],
     "vs_search_workspace_bytes": [_vp, _u32, _u64p],
     "vs_search_device": [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp],
+    "vs_search_batch_workspace_bytes": [_vp, _u32, _u64p],
+    "vs_search_batch_device": [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp],
     "vs_merge_topk_device": [_vp, _vp, _u32, _u32, _i32, _vp, _vp, _vp, _vp],
     "vs_merge_topk_batch_device": [_vp, _vp, _u32, _u64, _u32, _u64, _u32, _i32, _vp, _vp, _vp, _vp],
     "vs_roaring_to_mask": [_u8p, _sz, _u64p, _u64, _u64p],
@@ -263,6 +265,16 @@ class Store:
         b = ctypes.c_uint64(0)
         self._ck(lib.vs_search_workspace_bytes(self.handle, k, ctypes.byref(b)))
         return b.value
+
+    def batch_workspace_bytes(self, k):
+        b = ctypes.c_uint64(0)
+        self._ck(lib.vs_search_batch_workspace_bytes(self.handle, k, ctypes.byref(b)))
+        return b.value
+
+    def search_batch_device(self, d_queries, n_q, dim, k, d_mask, d_workspace, d_out_keys, stream=0):
+        """Batched bf16 matrix-core scan; raw device addresses, asynchronous on `stream`."""
+        self._ck(lib.vs_search_batch_device(self.handle, d_queries, n_q, dim, k, d_mask, d_workspace,
+                                            d_out_keys, stream))
 
     def search_device(self, d_query, dim, k, d_mask, d_workspace, d_out_keys, stream=0):
         """All arguments are raw device addresses (ints); asynchronous on `stream`."""

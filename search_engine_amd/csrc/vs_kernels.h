@@ -50,6 +50,17 @@ hipError_t launch_scan_hamming(const SlabView& s, const void* d_query, const uin
                                uint32_t* out_ids, float* out_dist, uint32_t* out_n,
                                const ScanTuning& t, hipStream_t stream);
 
+// Batched angular scan of a VS_BF16 slab on the matrix cores (vs_batch.hip): up to
+// 256 queries (f32 [n_q][dim] in device memory, rounded to bf16 by a prologue
+// kernel) share one pass over the rows. k <= VS_BATCH_MAX_K. `workspace` needs
+// batch_workspace_bytes bytes. Outputs as n_q consecutive blocks of k entries:
+// out_keys (nullable), out_ids / out_dist / out_n (nullable as a group).
+uint64_t batch_workspace_bytes(const SlabView& s, uint32_t k);
+hipError_t launch_scan_batch_bf16(const SlabView& s, const float* d_queries, uint32_t n_q,
+                                  const uint64_t* cand, uint32_t k, void* workspace,
+                                  uint64_t* out_keys, uint32_t* out_ids, float* out_dist,
+                                  uint32_t* out_n, hipStream_t stream);
+
 // ‖row‖₂ for slots [slot0, slot0 + n) of an angular slab, same summation order
 // as the scan uses for ⟨row, query⟩.
 hipError_t launch_norms(const SlabView& s, float* norms, uint64_t slot0, uint64_t n,

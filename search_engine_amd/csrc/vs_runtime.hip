@@ -61,6 +61,8 @@ struct Workspace {
     uint32_t* d_n = nullptr;
     uint8_t* d_blob = nullptr;
     size_t blob_bytes = 0;
+    unsigned char* d_batch = nullptr;  // batched path: queries, kernel workspace, results
+    size_t batch_bytes = 0;
     unsigned char* h_pinned = nullptr;  // query, then results
     size_t pinned_bytes = 0;
 
@@ -70,6 +72,7 @@ struct Workspace {
         if (d_partial) (void)hipFree(d_partial);
         if (d_keys) (void)hipFree(d_keys);
         if (d_blob) (void)hipFree(d_blob);
+        if (d_batch) (void)hipFree(d_batch);
         if (h_pinned) (void)hipHostFree(h_pinned);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -247,6 +250,47 @@ int32_t run_and_fetch(vs_store* s, Workspace* ws, const float* h_query, uint32_t
     memcpy(out_ids, hr, (size_t)n * 4);
     memcpy(out_dist, hr + (size_t)VS_MAX_K * 4, (size_t)n * 4);
     *out_n = n;
+    return VS_OK;
+}
+
+// Batched matrix-core path for bf16 stores: chunks of up to 256 queries, each one
+// pass over the rows.
+int32_t run_batch_and_fetch(vs_store* s, Workspace* ws, const float* h_queries, uint32_t n_q,
+                            uint32_t k, const uint64_t* d_cand, uint32_t* out_ids, float* out_dist,
+                            uint32_t* out_n) {
+    const vs::SlabView v = s->view();
+    const size_t chunk_q = VS_BATCH_MAX_QUERIES;
+    const size_t q_bytes = chunk_q * s->dim * 4;
+    const size_t res_bytes = chunk_q * k * 8 + chunk_q * 4;  // ids, distances, counts
+    const size_t ws_bytes = (size_t)vs::batch_workspace_bytes(v, k);
+    // one device block: queries | kernel workspace | results
+    const size_t off_ws = (q_bytes + 255) / 256 * 256, off_res = off_ws + (ws_bytes + 255) / 256 * 256;
+    if (int32_t rc = grow(&ws->d_batch, &ws->batch_bytes, off_res + res_bytes)) return rc;
+    std::vector<unsigned char> host(res_bytes);
+    for (uint32_t at = 0; at < n_q; at += (uint32_t)chunk_q) {
+        const uint32_t m = n_q - at < chunk_q ? n_q - at : (uint32_t)chunk_q;
+        float* d_q = reinterpret_cast<float*>(ws->d_batch);
+        uint32_t* d_ids = reinterpret_cast<uint32_t*>(ws->d_batch + off_res);
+        float* d_dist = reinterpret_cast<float*>(ws->d_batch + off_res + chunk_q * k * 4);
+        uint32_t* d_n = reinterpret_cast<uint32_t*>(ws->d_batch + off_res + chunk_q * k * 8);
+        HIP_TRY(hipMemcpyAsync(d_q, h_queries + (size_t)at * s->dim, (size_t)m * s->dim * 4,
+                               hipMemcpyHostToDevice, ws->stream));
+        HIP_TRY(vs::launch_scan_batch_bf16(v, d_q, m, d_cand, k, ws->d_batch + off_ws, nullptr, d_ids,
+                                           d_dist, d_n, ws->stream));
+        HIP_TRY(hipMemcpyAsync(host.data(), ws->d_batch + off_res, res_bytes, hipMemcpyDeviceToHost,
+                               ws->stream));
+        HIP_TRY(hipStreamSynchronize(ws->stream));
+        const uint32_t* h_ids = reinterpret_cast<const uint32_t*>(host.data());
+        const float* h_dist = reinterpret_cast<const float*>(host.data() + chunk_q * k * 4);
+        const uint32_t* h_n = reinterpret_cast<const uint32_t*>(host.data() + chunk_q * k * 8);
+        for (uint32_t i = 0; i < m; ++i) {
+            const uint32_t n = h_n[i];
+            if (n > k) return fail(VS_E_DEVICE, "device returned %u results for k = %u", n, k);
+            memcpy(out_ids + (size_t)(at + i) * k, h_ids + (size_t)i * k, (size_t)n * 4);
+            memcpy(out_dist + (size_t)(at + i) * k, h_dist + (size_t)i * k, (size_t)n * 4);
+            out_n[at + i] = n;
+        }
+    }
     return VS_OK;
 }
 
@@ -650,9 +694,13 @@ extern "C" int32_t vs_search_batch(vs_store* s, const float* queries, uint32_t n
         rc = stage_dense_mask(s, ws.get(), mask_words, n_mask_words);
         d_cand = ws->d_mask;
     }
-    for (uint32_t i = 0; i < n_q && rc == VS_OK; ++i)
-        rc = run_and_fetch(s, ws.get(), queries + (size_t)i * dim, k, d_cand, out_ids + (size_t)i * k,
-                           out_dist + (size_t)i * k, out_n + i);
+    if (rc == VS_OK && s->dtype == VS_BF16 && k <= VS_BATCH_MAX_K && n_q > 1) {
+        rc = run_batch_and_fetch(s, ws.get(), queries, n_q, k, d_cand, out_ids, out_dist, out_n);
+    } else {
+        for (uint32_t i = 0; i < n_q && rc == VS_OK; ++i)
+            rc = run_and_fetch(s, ws.get(), queries + (size_t)i * dim, k, d_cand, out_ids + (size_t)i * k,
+                               out_dist + (size_t)i * k, out_n + i);
+    }
     ws_release(s->ctx, std::move(ws));
     return rc;
 }
@@ -681,6 +729,35 @@ extern "C" int32_t vs_search_device(vs_store* s, const void* d_query, uint32_t d
     if (k == 0 || k > VS_MAX_K) return fail(VS_E_INVALID_ARG, "k = %u out of range", k);
     return launch_scan(s, d_query, d_mask_words, k, static_cast<uint64_t*>(d_workspace), d_out_keys,
                        nullptr, nullptr, nullptr, static_cast<hipStream_t>(hip_stream));
+}
+
+extern "C" int32_t vs_search_batch_workspace_bytes(vs_store* s, uint32_t k, uint64_t* bytes) {
+    if (!s || !bytes) return fail(VS_E_INVALID_ARG, "null argument");
+    if (s->dtype != VS_BF16) return fail(VS_E_INVALID_ARG, "the batched path needs a bf16 store");
+    if (k == 0 || k > VS_BATCH_MAX_K) return fail(VS_E_INVALID_ARG, "k = %u out of range", k);
+    *bytes = vs::batch_workspace_bytes(s->view(), k);
+    return VS_OK;
+}
+
+extern "C" int32_t vs_search_batch_device(vs_store* s, const float* d_queries, uint32_t n_q,
+                                          uint32_t dim, uint32_t k, const uint64_t* d_mask_words,
+                                          void* d_workspace, uint64_t* d_out_keys, void* hip_stream) {
+    if (int32_t rc = check_store(s)) return rc;
+    if (!d_queries || !d_workspace || !d_out_keys) return fail(VS_E_INVALID_ARG, "null device buffer");
+    if (!s->sealed.load()) return fail(VS_E_NOT_SEALED, "store %u was never sealed", s->index);
+    if (s->dtype != VS_BF16) return fail(VS_E_INVALID_ARG, "the batched path needs a bf16 store");
+    if (dim != s->dim) {
+        g_dim_expected = s->dim;
+        g_dim_received = dim;
+        return fail(VS_E_DIM_MISMATCH, "invalid vector dimensions: expected %u, received %u", s->dim,
+                    dim);
+    }
+    if (k == 0 || k > VS_BATCH_MAX_K || n_q == 0 || n_q > VS_BATCH_MAX_QUERIES)
+        return fail(VS_E_INVALID_ARG, "k = %u or n_q = %u out of range", k, n_q);
+    HIP_TRY(vs::launch_scan_batch_bf16(s->view(), d_queries, n_q, d_mask_words, k, d_workspace,
+                                       d_out_keys, nullptr, nullptr, nullptr,
+                                       static_cast<hipStream_t>(hip_stream)));
+    return VS_OK;
 }
 
 extern "C" int32_t vs_merge_topk_device(vs_ctx* ctx, const uint64_t* d_keys, uint32_t n_lists,

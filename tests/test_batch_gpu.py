@@ -1,0 +1,145 @@
+"""GPU parity tests of the batched bf16 scan on the matrix cores (vs_search_batch on a
+VS_BF16 store). No counterpart in the reference; the definition under test: rows AND
+queries rounded to bf16 (nearest even), arroy's Angular formula on the rounded values,
+f32 accumulation, results per query ascending by (distance, docid). The oracle gets the
+same rounded inputs; tolerances as in tests/helpers.py."""
+import numpy as np
+import pytest
+
+from conftest import facet_mask, synthetic_vectors
+from helpers import check_hits
+from oracle import scan as oracle
+
+pytestmark = pytest.mark.gpu
+
+_next_index = [0x5000]
+
+
+def make_bf16_store(ctx, vectors, docids=None, docid_base=0):
+    from search_engine_amd import abi
+    n, dim = vectors.shape
+    if docids is None:
+        docids = np.arange(n, dtype=np.uint32) + docid_base
+    _next_index[0] += 1
+    store = ctx.create_store(_next_index[0], dim, int(docids.max()) - docid_base + 1, dtype=abi.VS_BF16,
+                             docid_base=docid_base)
+    store.upload(docids, vectors)
+    store.seal()
+    return store
+
+
+def check_batch(store, vectors, queries, k, mask=None, docids=None):
+    n = vectors.shape[0]
+    if docids is None:
+        docids = np.arange(n, dtype=np.uint32)
+    rv, rq = oracle.bf16_round(vectors), oracle.bf16_round(queries)
+    results = store.search_batch(queries, k, mask)
+    assert len(results) == queries.shape[0]
+    ok = oracle.mask_to_bool(mask, int(docids.max()) + 1)[docids] if mask is not None else np.ones(n, bool)
+    swaps = 0
+    for (ids, dist), q in zip(results, rq):
+        o_ids, _ = oracle.nns_by_vector(rv, q, k, docids=docids, mask=mask)
+        d64 = dict(zip(docids.tolist(), oracle.all_distances_f64(rv, q).tolist()))
+        swaps += check_hits(ids, dist, o_ids, d64, k, int(ok.sum()))
+    return swaps
+
+
+@pytest.mark.parametrize("dim", [8, 24, 64, 100, 384, 768, 1536])
+def test_batch_parity_dimensions(gpu_ctx, dim):
+    n = 3000  # not a multiple of the 128-row tile
+    vectors = synthetic_vectors(n, dim, 700 + dim)
+    queries = synthetic_vectors(9, dim, 800 + dim)
+    store = make_bf16_store(gpu_ctx, vectors)
+    try:
+        check_batch(store, vectors, queries, 10, facet_mask(n, 50))
+    finally:
+        store.destroy()
+
+
+@pytest.mark.parametrize("n_q,k", [(2, 1), (7, 10), (64, 32), (256, 10), (300, 5)])
+def test_batch_parity_query_counts(gpu_ctx, n_q, k):
+    n, dim = 20000, 768
+    vectors = synthetic_vectors(n, dim, 0xBA7C)
+    queries = synthetic_vectors(n_q, dim, 44)
+    store = make_bf16_store(gpu_ctx, vectors)
+    try:
+        swaps = check_batch(store, vectors, queries, k, facet_mask(n, 10))
+        assert swaps <= max(2, n_q // 20)
+    finally:
+        store.destroy()
+
+
+@pytest.mark.parametrize("pass_percent", [None, 100, 1])
+def test_batch_parity_filters_and_holes(gpu_ctx, pass_percent):
+    dim, base = 128, 64 * 7
+    rng = np.random.default_rng(12)
+    docids = np.sort(rng.choice(20000, 6000, replace=False)).astype(np.uint32) + base
+    vectors = synthetic_vectors(docids.size, dim, 91)
+    vectors[5] = 0.0                                   # zero-norm row: distance 0 to everything
+    vectors[100:140] = vectors[99]                     # 41 identical rows: exact ties by docid
+    queries = synthetic_vectors(12, dim, 92)
+    queries[3] = 0.0                                   # zero query: every distance 0, order by docid
+    queries[4] = vectors[99] * 2
+    mask = None if pass_percent is None else facet_mask(base + 20000, pass_percent)
+    store = make_bf16_store(gpu_ctx, vectors, docids, docid_base=base)
+    try:
+        check_batch(store, vectors, queries, 32, mask, docids)
+    finally:
+        store.destroy()
+
+
+def test_batch_matches_single_query_ids(gpu_ctx):
+    """Same store, same (already bf16-exact) queries: the batched and the single-query path
+    agree on ids wherever distances are not within tolerance of each other."""
+    n, dim = 10000, 256
+    vectors = synthetic_vectors(n, dim, 5)
+    queries = oracle.bf16_round(synthetic_vectors(20, dim, 6))
+    store = make_bf16_store(gpu_ctx, vectors)
+    try:
+        batch = store.search_batch(queries, 10, None)
+        for (b_ids, b_dist), q in zip(batch, queries):
+            s_ids, s_dist = store.search(q, 10, None)
+            np.testing.assert_allclose(b_dist, s_dist, rtol=1e-5, atol=1e-6)
+            for a, b, da, db in zip(b_ids, s_ids, b_dist, s_dist):
+                assert a == b or abs(float(da) - float(db)) <= 2e-5 * abs(float(da)) + 2e-6
+    finally:
+        store.destroy()
+
+
+def test_batch_device_api_sharded(gpu_ctx):
+    """Two shards through vs_search_batch_device, keys gathered [shard][query][k], one merge launch."""
+    import torch
+    from search_engine_amd import abi
+    n, dim, k, n_q = 64 * 300, 64, 10, 33
+    vectors = synthetic_vectors(n, dim, 21)
+    queries = synthetic_vectors(n_q, dim, 22)
+    half = n // 2
+    whole = make_bf16_store(gpu_ctx, vectors)
+    a = make_bf16_store(gpu_ctx, vectors[:half])
+    b = make_bf16_store(gpu_ctx, vectors[half:], docid_base=half)
+    try:
+        ref = whole.search_batch(queries, k, None)
+        dev = torch.device("cuda:0")
+        d_q = torch.from_numpy(queries).to(dev)
+        keys = torch.empty(2 * n_q * k, dtype=torch.int64, device=dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        keep = []
+        for j, st in enumerate((a, b)):
+            ws = torch.empty(st.batch_workspace_bytes(k), dtype=torch.uint8, device=dev)
+            keep.append(ws)
+            st.search_batch_device(d_q.data_ptr(), n_q, dim, k, None, ws.data_ptr(),
+                                   keys.data_ptr() + 8 * n_q * k * j, stream)
+        ids = torch.empty(n_q * k, dtype=torch.int32, device=dev)
+        dist = torch.empty(n_q * k, dtype=torch.float32, device=dev)
+        cnt = torch.empty(n_q, dtype=torch.int32, device=dev)
+        gpu_ctx.merge_topk_batch_device(keys.data_ptr(), 2, n_q * k, n_q, k, k, abi.VS_ANGULAR,
+                                        ids.data_ptr(), dist.data_ptr(), cnt.data_ptr(), stream)
+        torch.cuda.synchronize()
+        ids = ids.cpu().numpy().astype(np.uint32).reshape(n_q, k)
+        dist = dist.cpu().numpy().reshape(n_q, k)
+        assert (cnt.cpu().numpy() == k).all()
+        for j, (r_ids, r_dist) in enumerate(ref):
+            assert ids[j].tolist() == r_ids.tolist() and dist[j].tolist() == r_dist.tolist()
+    finally:
+        for st in (whole, a, b):
+            st.destroy()
