@@ -27,17 +27,14 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 constexpr int BM = 128;      // documents per tile
 constexpr int BN = 256;      // queries per launch (padded)
 constexpr int BK = 64;       // bf16 elements per K step = 8 vectors of 16 bytes
-constexpr int CQCAP = 1024;  // candidate queue entries
 
-// LDS carve (bytes)
+// LDS carve (bytes). After a tile's K loop the A/B images are dead and the first
+// 32 KiB of them hold one 32-row chunk of scores, f32 [32][256].
 constexpr int OFF_A = 0;                       // [128][64] bf16, swizzled
 constexpr int OFF_B = OFF_A + BM * BK * 2;     // [256][64] bf16, swizzled
 constexpr int OFF_NORM = OFF_B + BN * BK * 2;  // f32[128] norms of the tile's rows
-constexpr int OFF_QUEUE = OFF_NORM + BM * 4;   // u64[CQCAP]
-constexpr int OFF_TAU = OFF_QUEUE + CQCAP * 8; // u64[256]
-constexpr int OFF_CTHR = OFF_TAU + BN * 8;     // f32[256]
-constexpr int OFF_CNT = OFF_CTHR + BN * 4;     // u32 count, u32 overflow
-constexpr int OFF_LISTS = OFF_CNT + 16;        // u64[k][256]
+constexpr int OFF_LISTS = OFF_NORM + BM * 4;   // u64[k][256], rank-major
+constexpr int OFF_SCORES = OFF_A;
 
 struct BatchArgs {
     const u32x4* rows;
@@ -71,26 +68,59 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
     const int k = (int)a.k;
 
     float* snorm = reinterpret_cast<float*>(smem + OFF_NORM);
-    volatile uint64_t* queue = reinterpret_cast<volatile uint64_t*>(smem + OFF_QUEUE);
-    volatile uint64_t* stau = reinterpret_cast<volatile uint64_t*>(smem + OFF_TAU);
-    volatile float* scthr = reinterpret_cast<volatile float*>(smem + OFF_CTHR);
-    uint32_t* scnt = reinterpret_cast<uint32_t*>(smem + OFF_CNT);
+    float* scores = reinterpret_cast<float*>(smem + OFF_SCORES);
     volatile uint64_t* lists = reinterpret_cast<volatile uint64_t*>(smem + OFF_LISTS);
 
-    // thread `tid` owns query `tid`: its list, its k-th best (tau) and the
-    // matching pre-test threshold
-    const bool owner = tid < (uint32_t)BN;
+    // thread `tid` < 256 owns query `tid`: its list, its k-th best (tau) and the
+    // matching pre-test threshold cthr
+    const bool owner = tid < a.n_q;
     const float my_qn = owner ? a.qnorm[tid] : 0.0f;
+    const float my_marg = my_qn * 1e-6f;
     uint64_t my_tau = KEY_NONE;
-    if (owner) {
+    float my_cthr = -__builtin_inff();
+    if (tid < (uint32_t)BN)
         for (int r = 0; r < k; ++r) lists[r * BN + tid] = KEY_NONE;
-        stau[tid] = KEY_NONE;
-        scthr[tid] = tid < a.n_q ? -__builtin_inff() : __builtin_inff();
-    }
     __syncthreads();
 
     const uint64_t n_words = a.n_slots >> 6;  // n_slots is a multiple of 64: the last tile may be half
     const uint32_t n_tiles = (uint32_t)((n_words + 1) / 2);
+    const uint32_t KS = a.ksteps;
+
+    // Document vectors are requested TWO K steps ahead of their use and query vectors one
+    // step ahead, across tile boundaries: (tile, ks) is one flat stream per workgroup.
+    auto load_a = [&](uint32_t tile, uint32_t ks, u32x4 (&dst)[2]) {
+        const uint64_t row0 = (uint64_t)tile * BM;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const uint32_t id = (uint32_t)it * BTHREADS + tid, row = id >> 3, slot = id & 7;
+            const uint32_t v = ks * 8 + slot;
+            dst[it] = (tile < n_tiles && v < a.row_vecs && row0 + row < a.n_slots)
+                          ? __builtin_nontemporal_load(a.rows + (row0 + row) * a.row_vecs + v)
+                          : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto load_b = [&](uint32_t ks, u32x4 (&dst)[4]) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const uint32_t id = (uint32_t)it * BTHREADS + tid, row = id >> 3, slot = id & 7;
+            dst[it] = a.qrows[(uint64_t)row * (KS * 8) + ks * 8 + slot];
+        }
+    };
+    // position p of the stream = K step (p % KS) of tile blockIdx.x + (p / KS) * gridDim.x
+    auto load_a_at = [&](uint32_t tile, uint32_t ks, uint32_t ahead, u32x4 (&dst)[2]) {
+        uint32_t k2 = ks + ahead, t2 = tile;
+        while (k2 >= KS) {
+            k2 -= KS;
+            t2 += gridDim.x;
+        }
+        load_a(t2, k2, dst);
+    };
+
+    u32x4 ga0[2], ga1[2], gb[4];
+    load_a_at(blockIdx.x, 0, 0, ga0);
+    load_a_at(blockIdx.x, 0, 1, ga1);
+    load_b(0, gb);
+
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t row0 = (uint64_t)tile * BM;
         const bool has1 = 2 * (uint64_t)tile + 1 < n_words;
@@ -101,7 +131,11 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
         }
         w0 = uniform_u64(w0);
         w1 = uniform_u64(w1);
-        if ((w0 | w1) == 0) continue;  // no candidate in this tile
+        if ((w0 | w1) == 0) {  // no candidate in this tile: restart the stream at the next one
+            load_a_at(tile + gridDim.x, 0, 0, ga0);
+            load_a_at(tile + gridDim.x, 0, 1, ga1);
+            continue;
+        }
 
         f32x16 acc[2][2];
 #pragma unroll
@@ -110,27 +144,9 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
             for (int n = 0; n < 2; ++n)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
-
-        u32x4 ga[2], gb[4];
-        auto gload = [&](uint32_t ks) {
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const uint32_t id = (uint32_t)it * BTHREADS + tid, row = id >> 3, slot = id & 7;
-                const uint32_t v = ks * 8 + slot;
-                ga[it] = (v < a.row_vecs && row0 + row < a.n_slots)
-                             ? __builtin_nontemporal_load(a.rows + (row0 + row) * a.row_vecs + v)
-                             : u32x4{0u, 0u, 0u, 0u};
-            }
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const uint32_t id = (uint32_t)it * BTHREADS + tid, row = id >> 3, slot = id & 7;
-                gb[it] = a.qrows[(uint64_t)row * (a.ksteps * 8) + ks * 8 + slot];
-            }
-        };
-        gload(0);
         if (tid < BM) snorm[tid] = row0 + tid < a.n_slots ? a.norms[row0 + tid] : 0.0f;
 
-        for (uint32_t ks = 0; ks < a.ksteps; ++ks) {
+        auto k_step = [&](uint32_t ks, u32x4 (&ga)[2]) {
             __syncthreads();  // everyone is done reading the previous step's image
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
@@ -143,7 +159,8 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
                 *reinterpret_cast<u32x4*>(smem + OFF_B + swz(id >> 3, id & 7)) = gb[it];
             }
             __syncthreads();
-            if (ks + 1 < a.ksteps) gload(ks + 1);  // in flight under the MFMAs below
+            load_a_at(tile, ks, 2, ga);                   // two steps ahead, in flight under the MFMAs
+            load_b(ks + 1 < KS ? ks + 1 : 0, gb);         // one step ahead (step 0 again for the next tile)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const uint32_t slot = (uint32_t)kk * 2 + half;
@@ -162,112 +179,77 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
                     for (int n = 0; n < 2; ++n)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
             }
+        };
+        // Even steps consume ga0, odd steps ga1. With an odd step count the roles of the two
+        // registers swap at every tile; `flip` keeps track.
+        for (uint32_t ks = 0; ks < KS; ks += 2) {
+            k_step(ks, ga0);
+            if (ks + 1 < KS) k_step(ks + 1, ga1);
+        }
+        if (KS & 1) {  // odd: the next tile's step 0 sits in ga1, its step 1 in ga0 -> swap
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const u32x4 t = ga0[it];
+                ga0[it] = ga1[it];
+                ga1[it] = t;
+            }
         }
 
         // ---- epilogue: which of this tile's 128 x 256 scores beat a query's k-th best? ----
-        // Pre-test without a division: d < dthr  <=>  pq > (1 - 2 dthr) * qn * pn, taken with a
-        // margin so that rounding can only let too many through; what passes is queued and
-        // judged exactly (arroy's formula, full (distance, docid) key) by the query's thread.
-        // Bit (m*2+n)*16 + e of `pend` = this lane's accumulator acc[m][n][e] is still to be judged.
-        uint64_t pend = 0;
+        // The scores go through LDS in four chunks of 32 rows; the thread that owns a query
+        // walks its column. Pre-test without a division: d < dthr  <=>  pq > (1 - 2 dthr) * qn * pn,
+        // taken with a margin so that rounding can only let too many through; what passes is
+        // judged exactly (arroy's formula, full (distance, docid) key) and inserted.
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            uint32_t vm = 0;  // validity of the lane's 16 rows of row block m
+        for (int c = 0; c < 4; ++c) {
+            __syncthreads();  // the K loop, or the previous chunk's readers, are done with this LDS
+            if (wm == (uint32_t)(c >> 1)) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const uint32_t row = wm * 64 + (uint32_t)m * 32 + (uint32_t)(e & 3) + 8u * (uint32_t)(e >> 2) + 4u * half;
-                const uint64_t wsel = row < 64 ? w0 >> row : w1 >> (row - 64);
-                vm |= (uint32_t)(wsel & 1ull) << e;
-            }
+                for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const uint32_t col = wn * 64 + (uint32_t)n * 32 + r32;
-                if (col < a.n_q) pend |= (uint64_t)vm << ((m * 2 + n) * 16);
-            }
-        }
-        for (;;) {
-            if (tid == 0) {
-                scnt[0] = 0;
-                scnt[1] = 0;
+                    for (int e = 0; e < 16; ++e) {
+                        const uint32_t row = (uint32_t)(e & 3) + 8u * (uint32_t)(e >> 2) + 4u * half;
+                        scores[row * BN + wn * 64 + (uint32_t)n * 32 + r32] = acc[c & 1][n][e];
+                    }
             }
             __syncthreads();
-            uint64_t pass = 0;
+            if (owner) {
+                const uint32_t bits = (uint32_t)((c < 2 ? w0 : w1) >> ((c & 1) * 32));
+                // all loads first, then one 32-bit mask of the rows that may beat tau
+                uint32_t pass = 0;
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
+                for (int g = 0; g < 8; ++g) {
+                    const f32x4v pn4 = *reinterpret_cast<const f32x4v*>(&snorm[c * 32 + g * 4]);
 #pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    const uint32_t col = wn * 64 + (uint32_t)n * 32 + r32;
-                    const float cthr = scthr[col];
-                    const float qmarg = a.qnorm[col] * 1e-6f;
-                    uint32_t pm = 0;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const uint32_t rowg = wm * 64 + (uint32_t)m * 32 + 8u * (uint32_t)g + 4u * half;
-                        const f32x4v pn4 = *reinterpret_cast<const f32x4v*>(&snorm[rowg]);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float pn = pn4[j];
-                            const float v = acc[m][n][g * 4 + j];
-                            if (!(v < cthr * pn - pn * qmarg)) pm |= 1u << (g * 4 + j);
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = scores[(g * 4 + j) * BN + tid];
+                        if (!(v < my_cthr * pn4[j] - pn4[j] * my_marg)) pass |= 1u << (g * 4 + j);
+                    }
+                }
+                pass &= bits;
+                while (pass) {  // rare after the first tiles
+                    const uint32_t r = (uint32_t)__builtin_ctz(pass);
+                    pass &= pass - 1;
+                    const float v = scores[r * BN + tid];
+                    const float pn = snorm[c * 32 + r];
+                    if (v < my_cthr * pn - pn * my_marg) continue;  // tau moved since the mask was taken
+                    const float pnqn = pn * my_qn;
+                    float d = 0.0f;
+                    if (pnqn != 0.0f) d = (1.0f - v / pnqn) / 2.0f;
+                    const uint64_t key = make_key(f32_orderable(d), a.docid_base + (uint32_t)(row0 + c * 32 + r));
+                    if (key < my_tau) {
+                        int pos = k - 1;
+                        while (pos > 0 && lists[(pos - 1) * BN + tid] > key) {
+                            lists[pos * BN + tid] = lists[(pos - 1) * BN + tid];
+                            --pos;
                         }
-                    }
-                    pass |= (uint64_t)pm << ((m * 2 + n) * 16);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            pass &= pend;
-            pend = 0;
-            while (pass) {  // rare: a lane walks the scores of its own that passed
-                const int bit = __builtin_ctzll(pass);
-                pass &= pass - 1;
-                float v = 0.0f;
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e)
-                            v = bit == (m * 2 + n) * 16 + e ? acc[m][n][e] : v;
-                const uint32_t e = (uint32_t)bit & 15u, n = ((uint32_t)bit >> 4) & 1u, m = (uint32_t)bit >> 5;
-                const uint32_t row = wm * 64 + m * 32 + (e & 3u) + 8u * (e >> 2) + 4u * half;
-                const uint32_t col = wn * 64 + n * 32 + r32;
-                const uint32_t idx = atomicAdd(&scnt[0], 1u);
-                if (idx < (uint32_t)CQCAP) {
-                    queue[idx] = ((uint64_t)__float_as_uint(v) << 32) | (row << 8) | col;
-                } else {
-                    scnt[1] = 1;  // queue full: judged in the next round
-                    pend |= 1ull << bit;
-                }
-            }
-            __syncthreads();
-            const uint32_t n_queued = scnt[0] < (uint32_t)CQCAP ? scnt[0] : (uint32_t)CQCAP;
-            const bool overflow = scnt[1] != 0;
-            for (uint32_t i = 0; owner && i < n_queued; ++i) {
-                const uint64_t ent = queue[i];
-                if ((uint32_t)(ent & 0xFF) != tid) continue;
-                const uint32_t row = (uint32_t)(ent >> 8) & 0x7F;
-                const float pq = __uint_as_float((uint32_t)(ent >> 32));
-                const float pn = snorm[row];
-                const float pnqn = pn * my_qn;
-                float d = 0.0f;
-                if (pnqn != 0.0f) d = (1.0f - pq / pnqn) / 2.0f;
-                const uint64_t key = make_key(f32_orderable(d), a.docid_base + (uint32_t)(row0 + row));
-                if (key < my_tau) {
-                    int pos = k - 1;
-                    while (pos > 0 && lists[(pos - 1) * BN + tid] > key) {
-                        lists[pos * BN + tid] = lists[(pos - 1) * BN + tid];
-                        --pos;
-                    }
-                    lists[pos * BN + tid] = key;
-                    my_tau = lists[(k - 1) * BN + tid];
-                    if (my_tau != KEY_NONE) {
-                        const float dthr = f32_from_orderable((uint32_t)(my_tau >> 32));
-                        scthr[tid] = (1.0f - 2.0f * dthr) * my_qn;
+                        lists[pos * BN + tid] = key;
+                        my_tau = lists[(k - 1) * BN + tid];
+                        if (my_tau != KEY_NONE)
+                            my_cthr = (1.0f - 2.0f * f32_from_orderable((uint32_t)(my_tau >> 32))) * my_qn;
                     }
                 }
             }
-            __syncthreads();
-            if (!overflow) break;
         }
     }
 
