@@ -3,16 +3,41 @@
 // request); it is the batch form of the same arroy Angular nns_by_vector result.
 //
 // Shape of the work: scores = Docs[N x D] * Queries[256 x D]^T is a real dense
-// contraction (2*N*D*256 flop for N*D*2 bytes: ~256 flop/byte), so it runs on the
+// contraction (2*N*D*256 flop for N*D*2 bytes: 256 flop/byte), so it runs on the
 // matrix cores: v_mfma_f32_32x32x16_bf16, f32 accumulation. The N x 256 score
-// matrix is never written: every 128-document tile is reduced on the spot into
+// matrix is never written: every 256-document tile is reduced on the spot into
 // per-query top-k lists that live in LDS for the whole launch.
 //
-// One workgroup = 8 waves (two per SIMD) = one 128-document x 256-query tile at a
-// time (wave tile 64 x 64 = 2 x 2 MFMA tiles, 64 accumulator registers);
-// workgroups are persistent and walk the tiles round-robin. K is walked in steps of 64: the
-// next step's 48 KiB (documents from HBM, queries from L2) are in flight in
-// registers while the current step's MFMAs run out of an XOR-swizzled LDS image.
+// One workgroup = 8 waves (two per SIMD) = one 256-document x 256-query tile at a
+// time (wave tile 64 x 128 = 2 x 4 MFMA tiles, 128 accumulator registers); a
+// workgroup walks its tiles in ascending order. K is walked in steps of 64: the
+// next step's 64 KiB (documents from HBM, queries from L2) are in flight while
+// the current step's MFMAs run out of an XOR-swizzled LDS image. A 256-row tile
+// re-reads the queries half as often as a 128-row tile would; that re-read and
+// the documents themselves, not the matrix cores, are what bound the kernel:
+// at 256 queries the contraction has 256 flop per document byte, below the
+// machine's ratio of matrix-core rate to HBM rate.
+//
+// Two builds of the kernel differ in how a step reaches LDS. DMA = true (k <= 12):
+// buffer loads write straight into one of TWO images (no staging registers, one
+// barrier per step, the next step's loads fly during the whole MFMA phase).
+// DMA = false (larger k: the lists need the LDS of the second image): the step
+// is staged in 32 registers per thread and stored into the one image between
+// two barriers.
+//
+// Selection. A launch may be given, per query, an upper bound on its k-th best
+// key (`bound_keys`): then almost no score survives, and the test runs on the
+// accumulator registers themselves -- t = score - |row| * c2[query] >= 0, where
+// c2 is the query's bound turned into a dot-product threshold, with a margin so
+// that rounding can only let too many through. Survivors go through a small LDS
+// queue to the thread that owns the query, which judges them exactly (arroy's
+// formula, full (distance, docid) key) and inserts them into its sorted list.
+// Without a bound, or when a tile overflows the queue, the tile's scores go
+// through LDS in four chunks of 64 rows and every owner walks its column.
+//
+// The launcher runs two passes: the first 256 tiles without a bound, a merge
+// that turns their lists into the per-query k-th best of that sample, and the
+// rest of the store with it as the bound.
 #include "vs_kernels.h"
 
 #include "../../include/vs_abi.h"
@@ -24,238 +49,418 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128;      // documents per tile
+constexpr int BM = 256;      // documents per tile
 constexpr int BN = 256;      // queries per launch (padded)
 constexpr int BK = 64;       // bf16 elements per K step = 8 vectors of 16 bytes
+constexpr int BTHREADS = 512;
+constexpr int QCAP = 256;    // survivors one tile may queue before it falls back to the chunked walk
+constexpr int SAMPLE_TILES = 256;  // tiles of the first (unbounded) pass
 
-// LDS carve (bytes). After a tile's K loop the A/B images are dead and the first
-// 32 KiB of them hold one 32-row chunk of scores, f32 [32][256].
-constexpr int OFF_A = 0;                       // [128][64] bf16, swizzled
-constexpr int OFF_B = OFF_A + BM * BK * 2;     // [256][64] bf16, swizzled
-constexpr int OFF_NORM = OFF_B + BN * BK * 2;  // f32[128] norms of the tile's rows
-constexpr int OFF_LISTS = OFF_NORM + BM * 4;   // u64[k][256], rank-major
-constexpr int OFF_SCORES = OFF_A;
+// LDS carve (bytes): `images` images of 64 KiB (A [256][64] bf16 at +0, B [256][64] bf16 at
+// +32 KiB, both swizzled), then the small arrays, then the lists. After a tile's K loop the
+// image it used last is dead and holds scores: one 64-row chunk f32 [64][256], or 8 KiB per wave.
+constexpr int IMG_BYTES = (BM + BN) * BK * 2;
+constexpr int IMG_B = BM * BK * 2;
+constexpr int OFF_NORM = 0;                       // f32[256] norms of the tile's rows (NaN: not a candidate)
+constexpr int OFF_C2 = OFF_NORM + BM * 4;         // f32[256] per-query pre-test threshold
+constexpr int OFF_QUEUE = OFF_C2 + BN * 4;        // u64[QCAP]: score bits << 32 | query << 8 | row
+constexpr int OFF_QCOUNT = OFF_QUEUE + QCAP * 8;  // u32[2], used by alternate tiles (16 bytes reserved)
+constexpr int OFF_QNORM = OFF_QCOUNT + 16;        // f32[256] query norms
+constexpr int OFF_BOUND = OFF_QNORM + BN * 4;     // u64[256] the bound each query started with
+constexpr int OFF_LISTS = OFF_BOUND + BN * 8;     // u64[k][256], rank-major
+constexpr uint32_t DMA_MAX_K = 12;
+
+constexpr size_t batch_lds_bytes(bool dma, uint32_t k) {
+    return (size_t)(dma ? 2 : 1) * IMG_BYTES + OFF_LISTS + (size_t)k * BN * 8;
+}
+static_assert(batch_lds_bytes(true, DMA_MAX_K) <= 160 * 1024 && batch_lds_bytes(false, VS_BATCH_MAX_K) <= 160 * 1024,
+              "LDS carve exceeds 160 KiB");
 
 struct BatchArgs {
     const u32x4* rows;
     const float* norms;
     const uint64_t* present;
     const uint64_t* cand;
-    const u32x4* qrows;   // [256][ksteps * 8] bf16 vectors, zero padded
-    const float* qnorm;   // [256]
-    uint64_t* partial;    // [n_q][gridDim.x][k]
+    const u32x4* qrows;          // [256][ksteps * 8] bf16 vectors, zero padded
+    const float* qnorm;          // [256]
+    const uint64_t* bound_keys;  // nullable: [n_q][k] ascending keys of an earlier pass over OTHER rows
+    uint64_t* partial;           // [n_q][lists][k]; list b = this launch's workgroup b
     uint64_t n_slots;
     uint32_t row_vecs;
     uint32_t ksteps;
     uint32_t docid_base;
     uint32_t k;
     uint32_t n_q;
+    uint32_t tile0, tile_end;  // tiles [tile0, tile_end) of 256 rows
+    uint32_t lists;            // gridDim.x, + 1 when bound_keys is carried along as a list of its own
 };
 
-// byte offset of 16-byte slot `slot` (0..7) of row `row` in a [rows][64] bf16 tile
+// Byte offset of 16-byte slot `slot` (0..7) of row `row` in a [rows][64] bf16 image.
+// ds_read_b128 serves lanes {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32) together:
+// with the slot XORed by (row >> 1) & 7 the 16 rows of each group hit 16 different
+// 16-byte bank groups, and the 8 lanes that store one row still cover its 8 slots.
 __device__ __forceinline__ uint32_t swz(uint32_t row, uint32_t slot) {
-    return row * 128u + ((slot ^ (row & 7u)) << 4);
+    return row * 128u + ((slot ^ ((row >> 1) & 7u)) << 4);
 }
 
-constexpr int BTHREADS = 512;
+// Returns x, but the compiler cannot see that: whatever is computed from the result is
+// computed where it is used, instead of being kept in a register across the K loop.
+__device__ __forceinline__ uint32_t opaque(uint32_t x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
 
+template <bool DMA>
 __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
+    unsigned char* const smem = lds_all + (DMA ? 2 : 1) * IMG_BYTES;  // the small arrays and the lists
     const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63, wv = tid >> 6;
-    const uint32_t wm = wv >> 2, wn = wv & 3;  // wave tile origin: rows wm*64, cols wn*64
+    const uint32_t lane = tid & 63, wv = uniform_u32(tid >> 6);
+    const uint32_t wm = wv >> 1, wn = wv & 1;  // wave tile origin: rows wm*64, cols wn*128
     const uint32_t r32 = lane & 31, half = lane >> 5;
     const int k = (int)a.k;
 
     float* snorm = reinterpret_cast<float*>(smem + OFF_NORM);
-    float* scores = reinterpret_cast<float*>(smem + OFF_SCORES);
-    volatile uint64_t* lists = reinterpret_cast<volatile uint64_t*>(smem + OFF_LISTS);
+    float* c2 = reinterpret_cast<float*>(smem + OFF_C2);
+    uint64_t* queue = reinterpret_cast<uint64_t*>(smem + OFF_QUEUE);
+    uint32_t* qcounts = reinterpret_cast<uint32_t*>(smem + OFF_QCOUNT);
+    // (plain pointers: a volatile one would be demoted to flat, system-scope accesses)
+    uint64_t* lists = reinterpret_cast<uint64_t*>(smem + OFF_LISTS);
 
-    // thread `tid` < 256 owns query `tid`: its list, its k-th best (tau) and the
-    // matching pre-test threshold cthr
+    // Thread `tid` < n_q owns query `tid`: its list, the key an entry must beat (tau =
+    // min(bound, k-th best so far)) and the matching pre-test threshold.
     const bool owner = tid < a.n_q;
-    const float my_qn = owner ? a.qnorm[tid] : 0.0f;
-    const float my_marg = my_qn * 1e-6f;
-    uint64_t my_tau = KEY_NONE;
-    float my_cthr = -__builtin_inff();
-    if (tid < (uint32_t)BN)
+    // (the norm and the bound are kept in LDS and re-read where they are needed: registers are
+    // dear in the K loop)
+    float* sqn = reinterpret_cast<float*>(smem + OFF_QNORM);
+    uint64_t* sbound = reinterpret_cast<uint64_t*>(smem + OFF_BOUND);
+    uint64_t my_tau = (owner && a.bound_keys) ? a.bound_keys[(uint64_t)tid * k + (k - 1)] : KEY_NONE;
+    int my_cnt = 0;  // entries in my list
+    // pq >= c2 * pn is necessary for a row to beat tau: d < dthr <=> pq > (1 - 2 dthr) qn pn.
+    auto threshold = [&](float qn) -> float {
+        if (my_tau == KEY_NONE) return -3.0e38f;
+        // a zero query is at distance 0 from everything: once tau is set no later (higher) docid beats it
+        if (qn == 0.0f) return 3.0e38f;
+        const float c = (1.0f - 2.0f * f32_from_orderable((uint32_t)(my_tau >> 32))) * qn - qn * 1e-6f;
+        return c == c ? c : -3.0e38f;
+    };
+    float my_c2;
+    bool bad_query;
+    {
+        const float qn = owner ? a.qnorm[tid] : 0.0f;
+        if (tid < (uint32_t)BN) {
+            sqn[tid] = qn;
+            sbound[tid] = my_tau;
+        }
+        my_c2 = threshold(qn);
+        bad_query = owner && !(qn < __builtin_inff());
+    }
+    if (tid < (uint32_t)BN) {
         for (int r = 0; r < k; ++r) lists[r * BN + tid] = KEY_NONE;
-    __syncthreads();
+        c2[tid] = owner ? my_c2 : 3.0e38f;
+    }
+    // a query with a non-finite norm defeats the register test: every tile then takes the chunked walk
+    const uint32_t qcount0 = __syncthreads_or(bad_query) ? (uint32_t)QCAP + 1u : 0u;
+    if (tid < 2) qcounts[tid] = qcount0;
+    uint32_t par = 0;  // which of the two survivor counters this tile uses; the other one is being reset
 
-    const uint64_t n_words = a.n_slots >> 6;  // n_slots is a multiple of 64: the last tile may be half
-    const uint32_t n_tiles = (uint32_t)((n_words + 1) / 2);
+    const uint64_t n_words = a.n_slots >> 6;
     const uint32_t KS = a.ksteps;
+    const bool col_ok[4] = {wn * 128 + 0 * 32 + r32 < a.n_q, wn * 128 + 1 * 32 + r32 < a.n_q,
+                            wn * 128 + 2 * 32 + r32 < a.n_q, wn * 128 + 3 * 32 + r32 < a.n_q};
 
-    // Document vectors are requested TWO K steps ahead of their use and query vectors one
-    // step ahead, across tile boundaries: (tile, ks) is one flat stream per workgroup.
-    auto load_a = [&](uint32_t tile, uint32_t ks, u32x4 (&dst)[2]) {
-        const uint64_t row0 = (uint64_t)tile * BM;
+    // judge one surviving score exactly and insert it into this thread's list
+    auto consider = [&](uint64_t row0, uint32_t row, float v) {
+        const float pn = snorm[row];
+        const float my_qn = sqn[tid];
+        const float pnqn = pn * my_qn;
+        float d = 0.0f;
+        if (pnqn != 0.0f) d = (1.0f - v / pnqn) / 2.0f;
+        const uint64_t key = make_key(f32_orderable(d), a.docid_base + (uint32_t)(row0 + row));
+        if (key < my_tau) {
+            int pos = my_cnt < k ? my_cnt : k - 1;  // slots past my_cnt are empty
+            my_cnt = pos + 1;
+            while (pos > 0 && lists[(pos - 1) * BN + tid] > key) {
+                lists[pos * BN + tid] = lists[(pos - 1) * BN + tid];
+                --pos;
+            }
+            lists[pos * BN + tid] = key;
+            const uint64_t kth = lists[(k - 1) * BN + tid], my_bound = sbound[tid];
+            my_tau = kth < my_bound ? kth : my_bound;
+            my_c2 = threshold(my_qn);
+            c2[tid] = my_c2;
+        }
+    };
+
+    // One K step of one tile = 64 KiB: slot (16 bytes) s of row r goes to byte swz(r, s) of its
+    // image. Buffer loads: a wave-uniform descriptor and scalar offset plus a 32-bit per-thread
+    // offset. A tile past the end gets an empty descriptor (reads zeros, touches nothing); the K
+    // tail of the last step is pushed out of range the same way. Rows past n_slots inside the
+    // last tile lie in the slab's padding: whatever they hold, they are not candidates.
+    const uint32_t row_bytes = a.row_vecs * 16u;
+    const __amdgpu_buffer_rsrc_t qres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<u32x4*>(a.qrows), 0, (int)((uint32_t)BN * KS * 128u), 0x00020000);
+    auto doc_rsrc = [&](uint32_t tile) {
+        const bool live = tile < a.tile_end;
+        return __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<u32x4*>(a.rows + (live ? (uint64_t)tile * BM * a.row_vecs : 0)), 0,
+            live ? (int)((uint32_t)BM * row_bytes) : 0, 0x00020000);
+    };
+    // DMA = false: thread t stages slot (t & 7) of rows (t >> 3) + 64 * it, it = 0..3, of both images
+    u32x4 ga[DMA ? 1 : 4], gb[DMA ? 1 : 4];
+    const uint32_t ld_row = tid >> 3, ld_slot = tid & 7;
+    const uint32_t voff_a = ld_row * row_bytes + ld_slot * 16u;
+    const uint32_t voff_b = ld_row * (KS * 128u) + ld_slot * 16u;
+    const uint32_t st_off = swz(ld_row, ld_slot);  // + it * 64 rows * 128 bytes: the swizzle repeats every 16 rows
+    // DMA = true: one load instruction fills 1 KiB of LDS in lane order = 8 rows of an image; wave
+    // w issues pieces 4w..4w+3 of each image. Lane l therefore fetches, for row (l >> 3) of the
+    // piece, the slot that belongs at physical position (l & 7): (l & 7) ^ ((row >> 1) & 7), which
+    // for piece 4w+i is (l & 7) ^ ((i & 1) * 4 + (l >> 4)).
+    const uint32_t dslot[2] = {(lane & 7) ^ (lane >> 4), (lane & 7) ^ (4 + (lane >> 4))};
+    const uint32_t dva[2] = {(lane >> 3) * row_bytes + dslot[0] * 16u, (lane >> 3) * row_bytes + dslot[1] * 16u};
+    const uint32_t dvb[2] = {(lane >> 3) * (KS * 128u) + dslot[0] * 16u, (lane >> 3) * (KS * 128u) + dslot[1] * 16u};
+    auto load_step = [&](uint32_t tile, uint32_t ks, uint32_t image) {
+        const __amdgpu_buffer_rsrc_t ares = doc_rsrc(tile);
+        if constexpr (DMA) {
+            typedef __attribute__((address_space(3))) void* lds_ptr;
+            unsigned char* img = lds_all + image * IMG_BYTES + wv * 4096;
+            const uint32_t kill[2] = {ks * 8 + dslot[0] < a.row_vecs ? 0u : 0x40000000u,
+                                      ks * 8 + dslot[1] < a.row_vecs ? 0u : 0x40000000u};
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const uint32_t id = (uint32_t)it * BTHREADS + tid, row = id >> 3, slot = id & 7;
-            const uint32_t v = ks * 8 + slot;
-            dst[it] = (tile < n_tiles && v < a.row_vecs && row0 + row < a.n_slots)
-                          ? __builtin_nontemporal_load(a.rows + (row0 + row) * a.row_vecs + v)
-                          : u32x4{0u, 0u, 0u, 0u};
-        }
-    };
-    auto load_b = [&](uint32_t ks, u32x4 (&dst)[4]) {
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(qres, (lds_ptr)(img + IMG_B + i * 1024), 16, (int)dvb[i & 1],
+                                                         (int)(ks * 128u + (wv * 4 + i) * 8u * (KS * 128u)), 0, 0);
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const uint32_t id = (uint32_t)it * BTHREADS + tid, row = id >> 3, slot = id & 7;
-            dst[it] = a.qrows[(uint64_t)row * (KS * 8) + ks * 8 + slot];
+            for (int i = 0; i < 4; ++i)  // nt: every document byte is read once per launch
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ares, (lds_ptr)(img + i * 1024), 16, (int)(dva[i & 1] | kill[i & 1]),
+                                                         (int)(ks * 128u + (wv * 4 + i) * 8u * row_bytes), 0, 2);
+        } else {
+            const uint32_t va = voff_a | (ks * 8 + ld_slot < a.row_vecs ? 0u : 0x40000000u);
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                gb[it] = __builtin_amdgcn_raw_buffer_load_b128(qres, (int)voff_b,
+                                                               (int)(ks * 128u + (uint32_t)it * 64u * (KS * 128u)), 0);
+#pragma unroll
+            for (int it = 0; it < 4; ++it)  // nt: every document byte is read once per launch
+                ga[it] = __builtin_amdgcn_raw_buffer_load_b128(ares, (int)va,
+                                                               (int)(ks * 128u + (uint32_t)it * 64u * row_bytes), 2);
         }
     };
-    // position p of the stream = K step (p % KS) of tile blockIdx.x + (p / KS) * gridDim.x
-    auto load_a_at = [&](uint32_t tile, uint32_t ks, uint32_t ahead, u32x4 (&dst)[2]) {
-        uint32_t k2 = ks + ahead, t2 = tile;
-        while (k2 >= KS) {
-            k2 -= KS;
-            t2 += gridDim.x;
-        }
-        load_a(t2, k2, dst);
-    };
 
-    u32x4 ga0[2], ga1[2], gb[4];
-    load_a_at(blockIdx.x, 0, 0, ga0);
-    load_a_at(blockIdx.x, 0, 1, ga1);
-    load_b(0, gb);
+    const uint32_t frag_a = swz(wm * 64 + r32, half), frag_b = IMG_B + swz(wn * 128 + r32, half);
+    uint32_t image = 0;  // DMA: the image the step about to be computed lands in
 
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    load_step(a.tile0 + blockIdx.x, 0, image);
+
+    for (uint32_t tile = a.tile0 + blockIdx.x; tile < a.tile_end; tile += gridDim.x) {
         const uint64_t row0 = (uint64_t)tile * BM;
-        const bool has1 = 2 * (uint64_t)tile + 1 < n_words;
-        uint64_t w0 = a.present[2 * (uint64_t)tile], w1 = has1 ? a.present[2 * (uint64_t)tile + 1] : 0;
-        if (a.cand) {
-            w0 &= a.cand[2 * (uint64_t)tile];
-            if (has1) w1 &= a.cand[2 * (uint64_t)tile + 1];
+        // this wave's 64 rows are exactly one word of the candidate mask
+        uint64_t w[4];
+        uint64_t any = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t wi = 4 * (uint64_t)tile + j;
+            uint64_t x = wi < n_words ? a.present[wi] : 0;
+            if (a.cand && wi < n_words) x &= a.cand[wi];
+            w[j] = uniform_u64(x);
+            any |= w[j];
         }
-        w0 = uniform_u64(w0);
-        w1 = uniform_u64(w1);
-        if ((w0 | w1) == 0) {  // no candidate in this tile: restart the stream at the next one
-            load_a_at(tile + gridDim.x, 0, 0, ga0);
-            load_a_at(tile + gridDim.x, 0, 1, ga1);
+        if (any == 0) {  // no candidate in this tile: restart the stream at the next one
+            if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the same image is about to be refilled
+            load_step(tile + gridDim.x, 0, image);
             continue;
         }
+        uint32_t* qcount = qcounts + par;
 
-        f32x16 acc[2][2];
+        f32x16 acc[2][4];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
+            for (int n = 0; n < 4; ++n)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
-        if (tid < BM) snorm[tid] = row0 + tid < a.n_slots ? a.norms[row0 + tid] : 0.0f;
 
-        auto k_step = [&](uint32_t ks, u32x4 (&ga)[2]) {
-            __syncthreads();  // everyone is done reading the previous step's image
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const uint32_t id = (uint32_t)it * BTHREADS + tid;
-                *reinterpret_cast<u32x4*>(smem + OFF_A + swz(id >> 3, id & 7)) = ga[it];
-            }
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const uint32_t id = (uint32_t)it * BTHREADS + tid;
-                *reinterpret_cast<u32x4*>(smem + OFF_B + swz(id >> 3, id & 7)) = gb[it];
-            }
+        for (uint32_t ks = 0; ks < KS; ++ks) {
+            if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): my pieces of this step are in LDS
+            // everyone's pieces are; the previous step's readers, or the previous tile's epilogue, are done
             __syncthreads();
-            load_a_at(tile, ks, 2, ga);                   // two steps ahead, in flight under the MFMAs
-            load_b(ks + 1 < KS ? ks + 1 : 0, gb);         // one step ahead (step 0 again for the next tile)
+            if (ks == 0) {
+                if (tid == 0) qcounts[par ^ 1] = qcount0;  // for the next tile; nobody reads it before then
+                if (tid < (uint32_t)BM) {
+                    // Rows that are not candidates get a NaN norm: their t is NaN, which the running
+                    // maximum ignores, and the chunked walk masks them by the candidate bits anyway.
+                    const bool is_cand = (w[tid >> 6] >> (tid & 63)) & 1;  // w[] index is wave-uniform
+                    const float pn = is_cand ? a.norms[row0 + tid] : 0.0f;
+                    snorm[tid] = is_cand ? pn : __builtin_nanf("");
+                    if (!(pn < __builtin_inff())) atomicAdd(qcount, (uint32_t)QCAP + 1u);  // as for a non-finite query
+                }
+            }
+            const unsigned char* img = lds_all;
+            if constexpr (DMA) {
+                img += image * IMG_BYTES;
+                image ^= 1u;
+                if (ks + 1 < KS)
+                    load_step(tile, ks + 1, image);
+                else
+                    load_step(tile + gridDim.x, 0, image);
+            } else {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    *reinterpret_cast<u32x4*>(lds_all + it * 64 * 128 + st_off) = ga[it];
+                    *reinterpret_cast<u32x4*>(lds_all + IMG_B + it * 64 * 128 + st_off) = gb[it];
+                }
+                __syncthreads();
+                if (ks + 1 < KS)
+                    load_step(tile, ks + 1, 0);
+                else
+                    load_step(tile + gridDim.x, 0, 0);
+            }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const uint32_t slot = (uint32_t)kk * 2 + half;
-                bf16x8 fa[2], fb[2];
+                // slot kk*2 + half of a row: the swizzled offset of slot `half`, XOR kk*32 bytes
+                uint32_t fo_a = frag_a ^ ((uint32_t)kk << 5), fo_b = frag_b ^ ((uint32_t)kk << 5);
+                asm volatile("" : "+v"(fo_a), "+v"(fo_b));  // recompute per step, do not keep 8 addresses live
+                bf16x8 fa[2], fb[4];
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
-                    fa[m] = __builtin_bit_cast(
-                        bf16x8, *reinterpret_cast<const u32x4*>(smem + OFF_A + swz(wm * 64 + m * 32 + r32, slot)));
+                    fa[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + m * 32 * 128 + fo_a));
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    fb[n] = __builtin_bit_cast(
-                        bf16x8, *reinterpret_cast<const u32x4*>(smem + OFF_B + swz(wn * 64 + n * 32 + r32, slot)));
+                for (int n = 0; n < 4; ++n)
+                    fb[n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + n * 32 * 128 + fo_b));
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int n = 0; n < 2; ++n)
+                    for (int n = 0; n < 4; ++n)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
             }
-        };
-        // Even steps consume ga0, odd steps ga1. With an odd step count the roles of the two
-        // registers swap at every tile; `flip` keeps track.
-        for (uint32_t ks = 0; ks < KS; ks += 2) {
-            k_step(ks, ga0);
-            if (ks + 1 < KS) k_step(ks + 1, ga1);
         }
-        if (KS & 1) {  // odd: the next tile's step 0 sits in ga1, its step 1 in ga0 -> swap
+        par ^= 1u;
+        // the image the last step used is dead now (after a barrier) and serves the epilogue
+        unsigned char* const epi = lds_all + (DMA ? (image ^ 1u) * IMG_BYTES : 0u);
+
+        // ---- register test: t = score - |row| * c2[query], per query column the largest t ----
+        // accumulator element e of MFMA tile (m, n) is row m*32 + (e&3) + 8*(e>>2) + 4*half,
+        // column n*32 + r32 of the wave tile
+        const bool reg_test = a.bound_keys != nullptr;  // without a bound everything would survive
+        if (reg_test) {
+            __syncthreads();  // every wave is out of the K loop: the image is free, each wave borrows 8 KiB of it
+            // f32 [32][64]: element (m*16+e) of every lane; `mine` points at this lane's column
+            float* mine = reinterpret_cast<float*>(epi + opaque(wv * 8192 + lane * 4));
+            const float* c2_mine = reinterpret_cast<const float*>(smem + OFF_C2 + opaque((wn * 128 + r32) * 4));
+            const float* norm_mine = reinterpret_cast<const float*>(smem + OFF_NORM + opaque((wm * 64 + 4 * half) * 4));
+            float c2v[4], tmax[4];
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const u32x4 t = ga0[it];
-                ga0[it] = ga1[it];
-                ga1[it] = t;
+            for (int n = 0; n < 4; ++n) {
+                c2v[n] = c2_mine[n * 32];
+                tmax[n] = -__builtin_inff();
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4v pn4 = *reinterpret_cast<const f32x4v*>(norm_mine + m * 32 + 8 * g);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int n = 0; n < 4; ++n)
+                            tmax[n] = __builtin_fmaxf(tmax[n], __builtin_fmaf(-pn4[j], c2v[n], acc[m][n][g * 4 + j]));
+                }
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const bool lane_hit = tmax[n] >= 0.0f && col_ok[n];
+                if (__ballot(lane_hit) == 0) continue;  // wave-uniform
+                // rare: park this MFMA column block in LDS, then the lanes with a hit look their 32 rows up again
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) mine[(m * 16 + e) * 64] = acc[m][n][e];
+                if (lane_hit && __hip_atomic_load(qcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= (uint32_t)QCAP) {
+#pragma unroll 8
+                    for (uint32_t i = 0; i < 32; ++i) {
+                        const uint32_t e = i & 15, r8 = (i >> 4) * 32 + (e & 3) + 8u * (e >> 2);
+                        const uint32_t wrow = r8 + 4u * half;
+                        const float v = mine[i * 64];
+                        if (__builtin_fmaf(-norm_mine[r8], c2v[n], v) >= 0.0f) {
+                            const uint32_t idx = atomicAdd(qcount, 1u);
+                            if (idx < (uint32_t)QCAP)
+                                queue[idx] = ((uint64_t)__float_as_uint(v) << 32) |
+                                             ((wn * 128 + (uint32_t)n * 32 + r32) << 8) | (wm * 64 + wrow);
+                        }
+                    }
+                }
             }
         }
+        __syncthreads();
+        const uint32_t n_queued = reg_test ? *qcount : (uint32_t)QCAP + 1u;
+        if (n_queued <= (uint32_t)QCAP) {
+            if (owner) {
+#pragma unroll 1
+                for (uint32_t i = 0; i < n_queued; i += 4) {  // (entries past n_queued are stale, never out of bounds)
+                    uint64_t e[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) e[j] = queue[(i + j) & (QCAP - 1)];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (i + j < n_queued && (((uint32_t)e[j] >> 8) & 0xFFFFFFu) == tid)
+                            consider(row0, (uint32_t)e[j] & 0xFFu, __uint_as_float((uint32_t)(e[j] >> 32)));
+                }
+            }
+            continue;  // the next tile's first barrier closes this epilogue
+        }
 
-        // ---- epilogue: which of this tile's 128 x 256 scores beat a query's k-th best? ----
-        // The scores go through LDS in four chunks of 32 rows; the thread that owns a query
-        // walks its column. Pre-test without a division: d < dthr  <=>  pq > (1 - 2 dthr) * qn * pn,
-        // taken with a margin so that rounding can only let too many through; what passes is
-        // judged exactly (arroy's formula, full (distance, docid) key) and inserted.
+        // ---- chunked walk: the scores go through LDS, 64 rows at a time; the thread that owns
+        // a query walks its column, pre-tests without a division and judges what passes ----
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            __syncthreads();  // the K loop, or the previous chunk's readers, are done with this LDS
-            if (wm == (uint32_t)(c >> 1)) {
+            if (c) __syncthreads();  // the previous chunk's readers are done with this LDS
+            if (wm == (uint32_t)c) {
+                // element (m, n, e) -> scores[m*32 + (e&3) + 8*(e>>2) + 4*half][wn*128 + n*32 + r32]
+                float* dst = reinterpret_cast<float*>(epi + opaque((4 * half * BN + wn * 128 + r32) * 4));
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
+                for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const uint32_t row = (uint32_t)(e & 3) + 8u * (uint32_t)(e >> 2) + 4u * half;
-                        scores[row * BN + wn * 64 + (uint32_t)n * 32 + r32] = acc[c & 1][n][e];
-                    }
+                    for (int n = 0; n < 4; ++n)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            dst[(m * 32 + (e & 3) + 8 * (e >> 2)) * BN + n * 32] = acc[m][n][e];
             }
             __syncthreads();
             if (owner) {
-                const uint32_t bits = (uint32_t)((c < 2 ? w0 : w1) >> ((c & 1) * 32));
-                // all loads first, then one 32-bit mask of the rows that may beat tau
-                uint32_t pass = 0;
+                const float* col = reinterpret_cast<const float*>(epi + opaque(tid * 4));
+                const float* norm_c = reinterpret_cast<const float*>(smem + OFF_NORM + opaque((uint32_t)c * 64 * 4));
 #pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    const f32x4v pn4 = *reinterpret_cast<const f32x4v*>(&snorm[c * 32 + g * 4]);
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t bits = (uint32_t)(w[c] >> (h * 32));
+                    // all loads first, then one 32-bit mask of the rows that may beat tau
+                    uint32_t pass = 0;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float v = scores[(g * 4 + j) * BN + tid];
-                        if (!(v < my_cthr * pn4[j] - pn4[j] * my_marg)) pass |= 1u << (g * 4 + j);
-                    }
-                }
-                pass &= bits;
-                while (pass) {  // rare after the first tiles
-                    const uint32_t r = (uint32_t)__builtin_ctz(pass);
-                    pass &= pass - 1;
-                    const float v = scores[r * BN + tid];
-                    const float pn = snorm[c * 32 + r];
-                    if (v < my_cthr * pn - pn * my_marg) continue;  // tau moved since the mask was taken
-                    const float pnqn = pn * my_qn;
-                    float d = 0.0f;
-                    if (pnqn != 0.0f) d = (1.0f - v / pnqn) / 2.0f;
-                    const uint64_t key = make_key(f32_orderable(d), a.docid_base + (uint32_t)(row0 + c * 32 + r));
-                    if (key < my_tau) {
-                        int pos = k - 1;
-                        while (pos > 0 && lists[(pos - 1) * BN + tid] > key) {
-                            lists[pos * BN + tid] = lists[(pos - 1) * BN + tid];
-                            --pos;
+                    for (int g = 0; g < 8; ++g) {
+                        const f32x4v pn4 = *reinterpret_cast<const f32x4v*>(norm_c + h * 32 + g * 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float v = col[(h * 32 + g * 4 + j) * BN];
+                            if (!(v < my_c2 * pn4[j])) pass |= 1u << (g * 4 + j);
                         }
-                        lists[pos * BN + tid] = key;
-                        my_tau = lists[(k - 1) * BN + tid];
-                        if (my_tau != KEY_NONE)
-                            my_cthr = (1.0f - 2.0f * f32_from_orderable((uint32_t)(my_tau >> 32))) * my_qn;
+                    }
+                    pass &= bits;
+                    while (pass) {
+                        const uint32_t r = (uint32_t)h * 32 + (uint32_t)__builtin_ctz(pass);
+                        pass &= pass - 1;
+                        const float v = col[r * BN];
+                        if (v < my_c2 * snorm[c * 64 + r]) continue;  // tau moved since the mask was taken
+                        consider(row0, (uint32_t)c * 64 + r, v);
                     }
                 }
             }
         }
     }
 
-    if (tid < a.n_q)
-        for (int r = 0; r < k; ++r)
-            a.partial[((uint64_t)tid * gridDim.x + blockIdx.x) * k + r] = lists[r * BN + tid];
+    if (tid < a.n_q) {
+        uint64_t* out = a.partial + (uint64_t)tid * a.lists * k;
+        for (int r = 0; r < k; ++r) out[(uint64_t)blockIdx.x * k + r] = lists[r * BN + tid];
+        if (a.bound_keys && blockIdx.x == 0)  // the earlier pass's list rides along as list gridDim.x
+            for (int r = 0; r < k; ++r) out[(uint64_t)gridDim.x * k + r] = a.bound_keys[(uint64_t)tid * k + r];
+    }
 }
 
 // queries f32 [n_q][dim] -> bf16 rows [256][kvecs * 8] (round to nearest even, zero
@@ -282,16 +487,37 @@ __global__ __launch_bounds__(256) void prep_queries_bf16_kernel(const float* que
     if (lane == 0) qnorm[j] = sqrtf(s);
 }
 
-uint32_t batch_grid_blocks(const SlabView& s) {
-    const uint64_t tiles = (s.n_slots + BM - 1) / BM;
-    return (uint32_t)(tiles < 1 ? 1 : tiles > 256 ? 256 : tiles);
+namespace {
+
+struct BatchPlan {
+    uint32_t ksteps, n_tiles, sample_tiles, blocks1, blocks2;
+    size_t off_qnorm, off_sample, off_partial1, off_partial2, total;
+};
+
+BatchPlan plan_batch(const SlabView& s, uint32_t k) {
+    BatchPlan p;
+    p.ksteps = (s.row_vecs + 7) / 8;
+    p.n_tiles = (uint32_t)((s.n_slots + BM - 1) / BM);
+    p.sample_tiles = p.n_tiles < (uint32_t)SAMPLE_TILES ? p.n_tiles : (uint32_t)SAMPLE_TILES;
+    p.blocks1 = p.sample_tiles < 1 ? 1 : p.sample_tiles;
+    const uint32_t rest = p.n_tiles - p.sample_tiles;
+    p.blocks2 = rest > 256 ? 256 : rest;
+    size_t off = (size_t)BN * p.ksteps * BK * 2;
+    p.off_qnorm = off;
+    off += (size_t)BN * 4 + 128;
+    p.off_sample = off;
+    off += (size_t)BN * k * 8;
+    p.off_partial1 = off;
+    off += (size_t)BN * p.blocks1 * k * 8;
+    p.off_partial2 = off;
+    off += (size_t)BN * (p.blocks2 + 1) * k * 8;
+    p.total = off + 256;
+    return p;
 }
 
-uint64_t batch_workspace_bytes(const SlabView& s, uint32_t k) {
-    const uint32_t ksteps = (s.row_vecs + 7) / 8;
-    return (uint64_t)BN * ksteps * BK * 2 + (uint64_t)BN * 4 +
-           (uint64_t)BN * batch_grid_blocks(s) * k * 8 + 256;
-}
+}  // namespace
+
+uint64_t batch_workspace_bytes(const SlabView& s, uint32_t k) { return plan_batch(s, k).total; }
 
 hipError_t launch_scan_batch_bf16(const SlabView& s, const float* d_queries, uint32_t n_q,
                                   const uint64_t* cand, uint32_t k, void* workspace,
@@ -300,13 +526,21 @@ hipError_t launch_scan_batch_bf16(const SlabView& s, const float* d_queries, uin
     if (s.dtype != VS_BF16 || k == 0 || k > VS_BATCH_MAX_K || n_q == 0 || n_q > (uint32_t)BN ||
         (s.n_slots & 63) != 0 || s.n_slots == 0)
         return hipErrorInvalidValue;
-    const uint32_t ksteps = (s.row_vecs + 7) / 8;
+    const BatchPlan p = plan_batch(s, k);
     unsigned char* ws = static_cast<unsigned char*>(workspace);
     uint16_t* qrows = reinterpret_cast<uint16_t*>(ws);
-    float* qnorm = reinterpret_cast<float*>(ws + (size_t)BN * ksteps * BK * 2);
-    uint64_t* partial = reinterpret_cast<uint64_t*>(ws + (size_t)BN * ksteps * BK * 2 + (size_t)BN * 4 + 128);
+    float* qnorm = reinterpret_cast<float*>(ws + p.off_qnorm);
+    uint64_t* sample = reinterpret_cast<uint64_t*>(ws + p.off_sample);
+    uint64_t* partial1 = reinterpret_cast<uint64_t*>(ws + p.off_partial1);
+    uint64_t* partial2 = reinterpret_cast<uint64_t*>(ws + p.off_partial2);
     hipLaunchKernelGGL(prep_queries_bf16_kernel, dim3(BN / 4), dim3(256), 0, stream, d_queries, n_q, s.dim,
-                       ksteps * BK, qrows, qnorm);
+                       p.ksteps * BK, qrows, qnorm);
+    const bool dma = k <= DMA_MAX_K;
+    const size_t lds = batch_lds_bytes(dma, k);
+    void (*kernel)(BatchArgs) = dma ? scan_batch_bf16_kernel<true> : scan_batch_bf16_kernel<false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
     BatchArgs a;
     a.rows = reinterpret_cast<const u32x4*>(s.rows);
     a.norms = s.norms;
@@ -314,23 +548,40 @@ hipError_t launch_scan_batch_bf16(const SlabView& s, const float* d_queries, uin
     a.cand = cand;
     a.qrows = reinterpret_cast<const u32x4*>(qrows);
     a.qnorm = qnorm;
-    a.partial = partial;
     a.n_slots = s.n_slots;
     a.row_vecs = s.row_vecs;
-    a.ksteps = ksteps;
+    a.ksteps = p.ksteps;
     a.docid_base = s.docid_base;
     a.k = k;
     a.n_q = n_q;
-    const uint32_t blocks = batch_grid_blocks(s);
-    const size_t lds = (size_t)OFF_LISTS + (size_t)k * BN * 8;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(scan_batch_bf16_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(scan_batch_bf16_kernel, dim3(blocks), dim3(BTHREADS), lds, stream, a);
+
+    // pass 1: the first tiles, no bound
+    const bool two = p.blocks2 > 0;
+    a.bound_keys = nullptr;
+    a.partial = partial1;
+    a.tile0 = 0;
+    a.tile_end = p.sample_tiles;
+    a.lists = p.blocks1;
+    hipLaunchKernelGGL(kernel, dim3(p.blocks1), dim3(BTHREADS), lds, stream, a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return launch_merge_batch(partial, blocks, k, 1, n_q, (uint64_t)blocks * k, k, VS_ANGULAR, out_keys,
-                              out_ids, out_dist, out_n, stream);
+    if (!two)
+        return launch_merge_batch(partial1, p.blocks1, k, 1, n_q, (uint64_t)p.blocks1 * k, k, VS_ANGULAR, out_keys,
+                                  out_ids, out_dist, out_n, stream);
+    e = launch_merge_batch(partial1, p.blocks1, k, 1, n_q, (uint64_t)p.blocks1 * k, k, VS_ANGULAR, sample, nullptr,
+                           nullptr, nullptr, stream);
+    if (e != hipSuccess) return e;
+    // pass 2: everything else, bounded by the sample's k-th best
+    a.bound_keys = sample;
+    a.partial = partial2;
+    a.tile0 = p.sample_tiles;
+    a.tile_end = p.n_tiles;
+    a.lists = p.blocks2 + 1;
+    hipLaunchKernelGGL(kernel, dim3(p.blocks2), dim3(BTHREADS), lds, stream, a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_merge_batch(partial2, p.blocks2 + 1, k, 1, n_q, (uint64_t)(p.blocks2 + 1) * k, k, VS_ANGULAR,
+                              out_keys, out_ids, out_dist, out_n, stream);
 }
 
 }  // namespace vs

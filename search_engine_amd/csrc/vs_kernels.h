@@ -10,8 +10,10 @@ namespace vs {
 // Geometry of a row slab in HBM. Rows are stored row-major, one row per
 // docid slot (slot = docid - docid_base), each row `row_vecs` 16-byte vectors
 // long and zero padded; `n_slots` is a multiple of 64.
+constexpr uint32_t SLAB_PAD_ROWS = 192;  // readable rows behind the last slot (contents irrelevant)
+
 struct SlabView {
-    const void* rows;         // n_slots * row_vecs * 16 bytes
+    const void* rows;         // (n_slots + SLAB_PAD_ROWS) * row_vecs * 16 bytes
     const float* norms;       // n_slots (angular stores), ‖row‖₂
     const uint64_t* present;  // n_slots / 64 words, bit set = slot holds an item
     uint64_t n_slots;

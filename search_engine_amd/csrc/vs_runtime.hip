@@ -415,7 +415,10 @@ extern "C" int32_t vs_store_create(vs_ctx* ctx, uint16_t store_index, uint32_t d
     s->n_slots = (capacity + 63) / 64 * 64;
     s->row_vecs = row_vecs;
     const size_t n_words = s->n_slots / 64;
-    HIP_TRY(hipMalloc(&s->d_rows, (size_t)s->n_slots * s->row_bytes()));
+    // 192 zeroed rows of padding: the batched scan reads whole 256-row tiles
+    HIP_TRY(hipMalloc(&s->d_rows, (size_t)(s->n_slots + vs::SLAB_PAD_ROWS) * s->row_bytes()));
+    HIP_TRY(hipMemset(static_cast<unsigned char*>(s->d_rows) + (size_t)s->n_slots * s->row_bytes(), 0,
+                      (size_t)vs::SLAB_PAD_ROWS * s->row_bytes()));
     HIP_TRY(hipMalloc(&s->d_present[0], n_words * 8));
     HIP_TRY(hipMalloc(&s->d_present[1], n_words * 8));
     HIP_TRY(hipMemset(s->d_present[0], 0, n_words * 8));

@@ -88,6 +88,29 @@ def test_batch_parity_filters_and_holes(gpu_ctx, pass_percent):
         store.destroy()
 
 
+@pytest.mark.parametrize("pass_percent,k", [(None, 10), (3, 10), (50, 32)])
+def test_batch_parity_beyond_the_sample_pass(gpu_ctx, pass_percent, k):
+    """More than 256 tiles of 256 rows: the first 65536 slots are scanned without a bound, the rest
+    against the k-th best of that sample (register test, survivor queue). The best rows are planted
+    at both ends, in the middle and in the padding-sized tail so that every path has to deliver."""
+    n, dim = 65536 * 2 + 64 * 3, 64
+    vectors = synthetic_vectors(n, dim, 0x7A11)
+    queries = synthetic_vectors(37, dim, 0x7A12)
+    rng = np.random.default_rng(5)
+    for j in range(queries.shape[0]):  # near-duplicates of each query scattered over the store
+        for pos in rng.choice(n, 6, replace=False):
+            vectors[pos] = queries[j] * (1.0 + 0.01 * rng.standard_normal()) + 0.05 * rng.standard_normal(dim).astype(np.float32)
+    vectors[n - 1] = queries[0]
+    vectors[70000] = 0.0          # zero-norm row in the bounded pass
+    queries[5] = 0.0              # zero query: first k candidate docids
+    mask = None if pass_percent is None else facet_mask(n, pass_percent)
+    store = make_bf16_store(gpu_ctx, vectors)
+    try:
+        check_batch(store, vectors, queries, k, mask)
+    finally:
+        store.destroy()
+
+
 def test_batch_matches_single_query_ids(gpu_ctx):
     """Same store, same (already bf16-exact) queries: the batched and the single-query path
     agree on ids wherever distances are not within tolerance of each other."""
