@@ -110,8 +110,13 @@ __device__ __forceinline__ uint32_t opaque(uint32_t x) {
     return x;
 }
 
-template <bool DMA>
+// FIRST = true is the build for the unbounded first pass: gridDim.x == number of tiles, one tile
+// per workgroup, so a query's list only exists after the K loop and lives in its owner's
+// registers (insertion is a chain of compare-exchanges, no LDS round trips). FIRST = false keeps
+// the lists in LDS across tiles; there insertions are rare.
+template <bool DMA, bool FIRST>
 __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) {
+    constexpr int KMAX = DMA ? (int)DMA_MAX_K : (int)VS_BATCH_MAX_K;  // k <= KMAX in this build
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
     unsigned char* const smem = lds_all + (DMA ? 2 : 1) * IMG_BYTES;  // the small arrays and the lists
     const uint32_t tid = threadIdx.x;
@@ -156,9 +161,14 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
         bad_query = owner && !(qn < __builtin_inff());
     }
     if (tid < (uint32_t)BN) {
-        for (int r = 0; r < k; ++r) lists[r * BN + tid] = KEY_NONE;
+        if constexpr (!FIRST)
+            for (int r = 0; r < k; ++r) lists[r * BN + tid] = KEY_NONE;
         c2[tid] = owner ? my_c2 : 3.0e38f;
     }
+    // FIRST: ascending, slots >= k hold 0 so that nothing ever sinks into them
+    uint64_t reg_list[FIRST ? KMAX : 1];
+#pragma unroll
+    for (int r = 0; r < (FIRST ? KMAX : 1); ++r) reg_list[r] = r < k ? KEY_NONE : 0;
     // a query with a non-finite norm defeats the register test: every tile then takes the chunked walk
     const uint32_t qcount0 = __syncthreads_or(bad_query) ? (uint32_t)QCAP + 1u : 0u;
     if (tid < 2) qcounts[tid] = qcount0;
@@ -178,14 +188,28 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
         if (pnqn != 0.0f) d = (1.0f - v / pnqn) / 2.0f;
         const uint64_t key = make_key(f32_orderable(d), a.docid_base + (uint32_t)(row0 + row));
         if (key < my_tau) {
-            int pos = my_cnt < k ? my_cnt : k - 1;  // slots past my_cnt are empty
-            my_cnt = pos + 1;
-            while (pos > 0 && lists[(pos - 1) * BN + tid] > key) {
-                lists[pos * BN + tid] = lists[(pos - 1) * BN + tid];
-                --pos;
+            uint64_t kth = KEY_NONE;
+            if constexpr (FIRST) {
+                uint64_t sink = key;  // sinks to its place, pushing every larger entry one slot down
+#pragma unroll
+                for (int r = 0; r < KMAX; ++r) {
+                    const bool lt = sink < reg_list[r];
+                    const uint64_t lo = lt ? sink : reg_list[r], hi = lt ? reg_list[r] : sink;
+                    reg_list[r] = lo;
+                    sink = hi;
+                    if (r == k - 1) kth = lo;
+                }
+            } else {
+                int pos = my_cnt < k ? my_cnt : k - 1;  // slots past my_cnt are empty
+                my_cnt = pos + 1;
+                while (pos > 0 && lists[(pos - 1) * BN + tid] > key) {
+                    lists[pos * BN + tid] = lists[(pos - 1) * BN + tid];
+                    --pos;
+                }
+                lists[pos * BN + tid] = key;
+                kth = lists[(k - 1) * BN + tid];
             }
-            lists[pos * BN + tid] = key;
-            const uint64_t kth = lists[(k - 1) * BN + tid], my_bound = sbound[tid];
+            const uint64_t my_bound = sbound[tid];
             my_tau = kth < my_bound ? kth : my_bound;
             my_c2 = threshold(my_qn);
             c2[tid] = my_c2;
@@ -343,9 +367,6 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
         // column n*32 + r32 of the wave tile
         const bool reg_test = a.bound_keys != nullptr;  // without a bound everything would survive
         if (reg_test) {
-            __syncthreads();  // every wave is out of the K loop: the image is free, each wave borrows 8 KiB of it
-            // f32 [32][64]: element (m*16+e) of every lane; `mine` points at this lane's column
-            float* mine = reinterpret_cast<float*>(epi + opaque(wv * 8192 + lane * 4));
             const float* c2_mine = reinterpret_cast<const float*>(smem + OFF_C2 + opaque((wn * 128 + r32) * 4));
             const float* norm_mine = reinterpret_cast<const float*>(smem + OFF_NORM + opaque((wm * 64 + 4 * half) * 4));
             float c2v[4], tmax[4];
@@ -369,24 +390,28 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
             for (int n = 0; n < 4; ++n) {
                 const bool lane_hit = tmax[n] >= 0.0f && col_ok[n];
                 if (__ballot(lane_hit) == 0) continue;  // wave-uniform
-                // rare: park this MFMA column block in LDS, then the lanes with a hit look their 32 rows up again
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) mine[(m * 16 + e) * 64] = acc[m][n][e];
+                // rare: which of this lane's 32 rows (bit m*16 + e), then queue them
+                uint32_t hit = 0;
                 if (lane_hit && __hip_atomic_load(qcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= (uint32_t)QCAP) {
-#pragma unroll 8
-                    for (uint32_t i = 0; i < 32; ++i) {
-                        const uint32_t e = i & 15, r8 = (i >> 4) * 32 + (e & 3) + 8u * (e >> 2);
-                        const uint32_t wrow = r8 + 4u * half;
-                        const float v = mine[i * 64];
-                        if (__builtin_fmaf(-norm_mine[r8], c2v[n], v) >= 0.0f) {
-                            const uint32_t idx = atomicAdd(qcount, 1u);
-                            if (idx < (uint32_t)QCAP)
-                                queue[idx] = ((uint64_t)__float_as_uint(v) << 32) |
-                                             ((wn * 128 + (uint32_t)n * 32 + r32) << 8) | (wm * 64 + wrow);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const float t = __builtin_fmaf(-norm_mine[m * 32 + (e & 3) + 8 * (e >> 2)], c2v[n], acc[m][n][e]);
+                            hit |= (t >= 0.0f) ? (1u << (m * 16 + e)) : 0u;
                         }
-                    }
+                }
+                while (hit) {
+                    const uint32_t i = (uint32_t)__builtin_ctz(hit);
+                    hit &= hit - 1;
+                    float v = acc[0][n][0];
+#pragma unroll
+                    for (int j = 1; j < 32; ++j) v = (i == (uint32_t)j) ? acc[j >> 4][n][j & 15] : v;
+                    const uint32_t e = i & 15, wrow = (i >> 4) * 32 + (e & 3) + 8u * (e >> 2) + 4u * half;
+                    const uint32_t idx = atomicAdd(qcount, 1u);
+                    if (idx < (uint32_t)QCAP)
+                        queue[idx] = ((uint64_t)__float_as_uint(v) << 32) |
+                                     ((wn * 128 + (uint32_t)n * 32 + r32) << 8) | (wm * 64 + wrow);
                 }
             }
         }
@@ -453,11 +478,18 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
                 }
             }
         }
+        if constexpr (FIRST) break;  // one tile per workgroup
     }
 
     if (tid < a.n_q) {
         uint64_t* out = a.partial + (uint64_t)tid * a.lists * k;
-        for (int r = 0; r < k; ++r) out[(uint64_t)blockIdx.x * k + r] = lists[r * BN + tid];
+        if constexpr (FIRST) {
+#pragma unroll
+            for (int r = 0; r < KMAX; ++r)
+                if (r < k) out[(uint64_t)blockIdx.x * k + r] = reg_list[r];
+        } else {
+            for (int r = 0; r < k; ++r) out[(uint64_t)blockIdx.x * k + r] = lists[r * BN + tid];
+        }
         if (a.bound_keys && blockIdx.x == 0)  // the earlier pass's list rides along as list gridDim.x
             for (int r = 0; r < k; ++r) out[(uint64_t)gridDim.x * k + r] = a.bound_keys[(uint64_t)tid * k + r];
     }
@@ -537,9 +569,13 @@ hipError_t launch_scan_batch_bf16(const SlabView& s, const float* d_queries, uin
                        p.ksteps * BK, qrows, qnorm);
     const bool dma = k <= DMA_MAX_K;
     const size_t lds = batch_lds_bytes(dma, k);
-    void (*kernel)(BatchArgs) = dma ? scan_batch_bf16_kernel<true> : scan_batch_bf16_kernel<false>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+    // (k > 12: a register list would spill; the general build serves both passes)
+    void (*first)(BatchArgs) = dma ? scan_batch_bf16_kernel<true, true> : scan_batch_bf16_kernel<false, false>;
+    void (*kernel)(BatchArgs) = dma ? scan_batch_bf16_kernel<true, false> : scan_batch_bf16_kernel<false, false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(first),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     BatchArgs a;
     a.rows = reinterpret_cast<const u32x4*>(s.rows);
@@ -562,7 +598,7 @@ hipError_t launch_scan_batch_bf16(const SlabView& s, const float* d_queries, uin
     a.tile0 = 0;
     a.tile_end = p.sample_tiles;
     a.lists = p.blocks1;
-    hipLaunchKernelGGL(kernel, dim3(p.blocks1), dim3(BTHREADS), lds, stream, a);
+    hipLaunchKernelGGL(first, dim3(p.blocks1), dim3(BTHREADS), lds, stream, a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (!two)
