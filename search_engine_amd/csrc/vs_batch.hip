@@ -369,11 +369,11 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
         if (reg_test) {
             const float* c2_mine = reinterpret_cast<const float*>(smem + OFF_C2 + opaque((wn * 128 + r32) * 4));
             const float* norm_mine = reinterpret_cast<const float*>(smem + OFF_NORM + opaque((wm * 64 + 4 * half) * 4));
-            float c2v[4], tmax[4];
+            float c2v[4], tmax[2][4];  // per MFMA tile (m, n): the largest t of this lane's 16 rows
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 c2v[n] = c2_mine[n * 32];
-                tmax[n] = -__builtin_inff();
+                tmax[0][n] = tmax[1][n] = -__builtin_inff();
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m)
@@ -384,36 +384,36 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
                         for (int n = 0; n < 4; ++n)
-                            tmax[n] = __builtin_fmaxf(tmax[n], __builtin_fmaf(-pn4[j], c2v[n], acc[m][n][g * 4 + j]));
+                            tmax[m][n] = __builtin_fmaxf(tmax[m][n], __builtin_fmaf(-pn4[j], c2v[n], acc[m][n][g * 4 + j]));
                 }
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const bool lane_hit = tmax[n] >= 0.0f && col_ok[n];
-                if (__ballot(lane_hit) == 0) continue;  // wave-uniform
-                // rare: which of this lane's 32 rows (bit m*16 + e), then queue them
-                uint32_t hit = 0;
-                if (lane_hit && __hip_atomic_load(qcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= (uint32_t)QCAP) {
+            for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int m = 0; m < 2; ++m)
+                for (int n = 0; n < 4; ++n) {
+                    const bool lane_hit = tmax[m][n] >= 0.0f && col_ok[n];
+                    if (__ballot(lane_hit) == 0) continue;  // wave-uniform
+                    // rare: which of this lane's 16 rows (bit e), then queue them
+                    uint32_t hit = 0;
+                    if (lane_hit && __hip_atomic_load(qcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= (uint32_t)QCAP) {
 #pragma unroll
                         for (int e = 0; e < 16; ++e) {
                             const float t = __builtin_fmaf(-norm_mine[m * 32 + (e & 3) + 8 * (e >> 2)], c2v[n], acc[m][n][e]);
-                            hit |= (t >= 0.0f) ? (1u << (m * 16 + e)) : 0u;
+                            hit |= (t >= 0.0f) ? (1u << e) : 0u;
                         }
-                }
-                while (hit) {
-                    const uint32_t i = (uint32_t)__builtin_ctz(hit);
-                    hit &= hit - 1;
-                    float v = acc[0][n][0];
+                    }
+                    while (hit) {
+                        const uint32_t e = (uint32_t)__builtin_ctz(hit);
+                        hit &= hit - 1;
+                        float v = acc[m][n][0];
 #pragma unroll
-                    for (int j = 1; j < 32; ++j) v = (i == (uint32_t)j) ? acc[j >> 4][n][j & 15] : v;
-                    const uint32_t e = i & 15, wrow = (i >> 4) * 32 + (e & 3) + 8u * (e >> 2) + 4u * half;
-                    const uint32_t idx = atomicAdd(qcount, 1u);
-                    if (idx < (uint32_t)QCAP)
-                        queue[idx] = ((uint64_t)__float_as_uint(v) << 32) |
-                                     ((wn * 128 + (uint32_t)n * 32 + r32) << 8) | (wm * 64 + wrow);
+                        for (int j = 1; j < 16; ++j) v = (e == (uint32_t)j) ? acc[m][n][j] : v;
+                        const uint32_t wrow = (uint32_t)m * 32 + (e & 3) + 8u * (e >> 2) + 4u * half;
+                        const uint32_t idx = atomicAdd(qcount, 1u);
+                        if (idx < (uint32_t)QCAP)
+                            queue[idx] = ((uint64_t)__float_as_uint(v) << 32) |
+                                         ((wn * 128 + (uint32_t)n * 32 + r32) << 8) | (wm * 64 + wrow);
+                    }
                 }
-            }
         }
         __syncthreads();
         const uint32_t n_queued = reg_test ? *qcount : (uint32_t)QCAP + 1u;
