@@ -94,7 +94,7 @@ __device__ __forceinline__ uint64_t make_key(uint32_t ordered_distance, uint32_t
 // `list` holds `k` keys ascending (KEY_NONE = empty slot) and belongs to ONE
 // wave. Inserts the wave-uniform `key`, which the caller has checked to be
 // smaller than list[k-1]; the last entry drops out. Returns the new list[k-1].
-__device__ __forceinline__ uint64_t list_insert(volatile uint64_t* list, int k, uint64_t key,
+__device__ __forceinline__ uint64_t list_insert(uint64_t* list, int k, uint64_t key,
                                                 int lane) {
     int pos = 0;
     for (int base = 0; base < k; base += 64) {
@@ -134,13 +134,13 @@ __device__ __forceinline__ uint64_t wave_shift_up_u64(uint64_t v, uint64_t fill)
 // keys are held): only keys below it may be inserted.
 struct WaveTopK {
     static constexpr int REG_K = 128;
-    volatile uint64_t* lds;  // k entries owned by this wave
+    uint64_t* lds;  // k entries owned by this wave
     int k, lane;
     bool in_regs;
     uint64_t lo, hi;  // entries lane and 64 + lane
     uint64_t tau;
 
-    __device__ __forceinline__ void init(volatile uint64_t* lds_, int k_, int lane_) {
+    __device__ __forceinline__ void init(uint64_t* lds_, int k_, int lane_) {
         lds = lds_;
         k = k_;
         lane = lane_;
@@ -178,7 +178,7 @@ struct WaveTopK {
         }
     }
     // inserts every entry below tau of another wave's spilled list
-    __device__ __forceinline__ void absorb(volatile uint64_t* other) {
+    __device__ __forceinline__ void absorb(uint64_t* other) {
         for (int j = 0; j < k; ++j) {
             const uint64_t key = uniform_u64(other[j]);
             if (key >= tau) break;

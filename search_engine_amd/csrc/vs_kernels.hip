@@ -115,7 +115,7 @@ template <int GROUP, typename ScoreFn>
 __device__ __forceinline__ void scan_masked_slots(const uint64_t* __restrict__ present,
                                                   const uint64_t* __restrict__ cand,
                                                   uint64_t n_slots, uint32_t w, uint32_t W, int lane,
-                                                  volatile uint32_t* queue, ScoreFn&& score) {
+                                                  uint32_t* queue, ScoreFn&& score) {
     static_assert(GROUP <= QCAP - 64, "queue too small");
     const uint64_t n_words = n_slots >> 6;
     const uint64_t my_words = w < n_words ? (n_words - w + W - 1) / W : 0;
@@ -171,7 +171,7 @@ __device__ __forceinline__ void finish_block(WaveTopK& top, unsigned char* smem,
     __syncthreads();
     if (wib == 0) {
         for (int v = 1; v < WAVES; ++v)
-            top.absorb(reinterpret_cast<volatile uint64_t*>(smem) + (size_t)v * k);
+            top.absorb(reinterpret_cast<uint64_t*>(smem) + (size_t)v * k);
         for (int base = 0; base < k; base += 64) {
             const int i = base + lane;
             const uint64_t key = top.at_lane(base);
@@ -190,10 +190,10 @@ __global__ __launch_bounds__(WAVES * 64) void scan_angular_kernel(ScanArgs a) {
     const uint32_t w = blockIdx.x * WAVES + wib;
     const int k = (int)a.k;
 
-    volatile uint32_t* queue =
-        reinterpret_cast<volatile uint32_t*>(smem + (size_t)WAVES * k * 8) + (size_t)wib * QCAP;
+    uint32_t* queue =
+        reinterpret_cast<uint32_t*>(smem + (size_t)WAVES * k * 8) + (size_t)wib * QCAP;
     WaveTopK top;
-    top.init(reinterpret_cast<volatile uint64_t*>(smem) + (size_t)wib * k, k, lane);
+    top.init(reinterpret_cast<uint64_t*>(smem) + (size_t)wib * k, k, lane);
 
     // this lane's slice of the query, and ‖q‖ summed in the row order
     float q[NCH][EPV];
@@ -280,10 +280,10 @@ __global__ __launch_bounds__(WAVES * 64) void scan_hamming_kernel(HammingArgs a)
     const uint32_t W = gridDim.x * WAVES;
     const uint32_t w = blockIdx.x * WAVES + wib;
     const int k = (int)a.k;
-    volatile uint32_t* queue =
-        reinterpret_cast<volatile uint32_t*>(smem + (size_t)WAVES * k * 8) + (size_t)wib * QCAP;
+    uint32_t* queue =
+        reinterpret_cast<uint32_t*>(smem + (size_t)WAVES * k * 8) + (size_t)wib * QCAP;
     WaveTopK top;
-    top.init(reinterpret_cast<volatile uint64_t*>(smem) + (size_t)wib * k, k, lane);
+    top.init(reinterpret_cast<uint64_t*>(smem) + (size_t)wib * k, k, lane);
 
     // this lane's share of the query: vectors sub, sub + 4, ...
     u32x4 q[NI];
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void merge_kernel(const uint64_t* keys, uint32
     const uint32_t wv = uniform_u32(threadIdx.x >> 6);
     const int k = (int)k_;
     WaveTopK top;
-    top.init(reinterpret_cast<volatile uint64_t*>(smem) + (size_t)wv * k, k, lane);
+    top.init(reinterpret_cast<uint64_t*>(smem) + (size_t)wv * k, k, lane);
 
     for (uint32_t base = 0; base < n_lists; base += 1024) {
         auto load_rank = [&](uint32_t r, uint64_t (&dst)[4]) {
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void merge_kernel(const uint64_t* keys, uint32
     __syncthreads();
     if (wv == 0) {
         for (int v = 1; v < 4; ++v)
-            top.absorb(reinterpret_cast<volatile uint64_t*>(smem) + (size_t)v * k);
+            top.absorb(reinterpret_cast<uint64_t*>(smem) + (size_t)v * k);
         uint32_t n = 0;
         for (int base = 0; base < k; base += 64) {
             const int i = base + lane;
