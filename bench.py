@@ -192,6 +192,21 @@ def main():
     d = out["dist"].view(qps_batch, k).cpu().numpy()
     assert (out["n"].cpu().numpy() == k).all() and (np.diff(d, axis=1) >= 0).all(), "malformed results"
 
+    # what a plain device-to-device copy reaches on this GPU (bytes read + bytes written), for scale
+    copy_gbps = None
+    if rank == 0:
+        src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbps = 5 * 2 * src.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(sample, queries, args, dim, k)
@@ -235,6 +250,8 @@ def main():
                 "kernel": "scan_angular_kernel (+ its merge launch)",
                 "algorithmic_bytes_per_launch": head["algo_bytes"],
                 "avg_launch_ms": round(head["scan_ms"], 4),
+                "measured_copy_gbps": round(copy_gbps, 1),
+                "frac_of_measured_copy": round(head["achieved_gbps"] / copy_gbps, 4),
             },
             "cpu_baseline": cpu,
             "sweep": sweep,

@@ -16,19 +16,51 @@ namespace search_engine {
 
 DocSet DocSet::from_ids(const std::vector<DocumentId>& ids) {
     DocSet s;
-    for (DocumentId d : ids) s.insert(d);
+    if (ids.size() <= SMALL_MAX) {
+        s.ids_ = ids;
+        std::sort(s.ids_.begin(), s.ids_.end());
+        s.ids_.erase(std::unique(s.ids_.begin(), s.ids_.end()), s.ids_.end());
+    } else {
+        s.small_ = false;
+        for (DocumentId d : ids) s.insert(d);
+    }
     return s;
 }
 DocSet DocSet::from_words(std::vector<uint64_t> words) {
     DocSet s;
+    s.small_ = false;
     s.w_ = std::move(words);
     return s;
 }
+void DocSet::densify() const {  // fills w_ from ids_
+    w_.assign(ids_.empty() ? 0 : (size_t)(ids_.back() >> 6) + 1, 0);
+    for (DocumentId d : ids_) w_[d >> 6] |= 1ull << (d & 63);
+}
+const std::vector<uint64_t>& DocSet::words() const {
+    if (small_ && !w_valid_) {
+        densify();
+        w_valid_ = true;
+    }
+    return w_;
+}
 bool DocSet::contains(DocumentId d) const {
+    if (small_) return std::binary_search(ids_.begin(), ids_.end(), d);
     const size_t wi = d >> 6;
     return wi < w_.size() && ((w_[wi] >> (d & 63)) & 1);
 }
 bool DocSet::insert(DocumentId d) {
+    if (small_) {
+        auto it = std::lower_bound(ids_.begin(), ids_.end(), d);
+        if (it != ids_.end() && *it == d) return false;
+        if (ids_.size() < SMALL_MAX) {
+            ids_.insert(it, d);
+            w_valid_ = false;
+            return true;
+        }
+        densify();
+        small_ = false;
+        ids_.clear();
+    }
     const size_t wi = d >> 6;
     if (wi >= w_.size()) w_.resize(wi + 1, 0);
     const uint64_t bit = 1ull << (d & 63);
@@ -37,6 +69,13 @@ bool DocSet::insert(DocumentId d) {
     return fresh;
 }
 bool DocSet::remove(DocumentId d) {
+    if (small_) {
+        auto it = std::lower_bound(ids_.begin(), ids_.end(), d);
+        if (it == ids_.end() || *it != d) return false;
+        ids_.erase(it);
+        w_valid_ = false;
+        return true;
+    }
     const size_t wi = d >> 6;
     if (wi >= w_.size()) return false;
     const uint64_t bit = 1ull << (d & 63);
@@ -45,17 +84,27 @@ bool DocSet::remove(DocumentId d) {
     return had;
 }
 uint64_t DocSet::len() const {
+    if (small_) return ids_.size();
     uint64_t n = 0;
     for (uint64_t w : w_) n += (uint64_t)__builtin_popcountll(w);
     return n;
 }
 bool DocSet::is_empty() const {
+    if (small_) return ids_.empty();
     for (uint64_t w : w_)
         if (w) return false;
     return true;
 }
 DocSet DocSet::operator&(const DocSet& o) const {
     DocSet r;
+    if (small_ || o.small_) {  // walk the small one, probe the other
+        const DocSet& a = small_ ? *this : o;
+        const DocSet& b = small_ ? o : *this;
+        for (DocumentId d : a.ids_)
+            if (b.contains(d)) r.ids_.push_back(d);
+        return r;
+    }
+    r.small_ = false;
     r.w_.resize(std::min(w_.size(), o.w_.size()));
     for (size_t i = 0; i < r.w_.size(); ++i) r.w_[i] = w_[i] & o.w_[i];
     return r;
@@ -66,16 +115,35 @@ DocSet DocSet::operator|(const DocSet& o) const {
     return r;
 }
 DocSet& DocSet::operator|=(const DocSet& o) {
+    if (o.small_) {
+        for (DocumentId d : o.ids_) insert(d);
+        return *this;
+    }
+    if (small_) {  // becomes dense
+        densify();
+        small_ = false;
+        ids_.clear();
+    }
     if (o.w_.size() > w_.size()) w_.resize(o.w_.size(), 0);
     for (size_t i = 0; i < o.w_.size(); ++i) w_[i] |= o.w_[i];
     return *this;
 }
 DocSet& DocSet::operator-=(const DocSet& o) {
+    if (small_) {
+        ids_.erase(std::remove_if(ids_.begin(), ids_.end(), [&](DocumentId d) { return o.contains(d); }), ids_.end());
+        w_valid_ = false;
+        return *this;
+    }
+    if (o.small_) {
+        for (DocumentId d : o.ids_) remove(d);
+        return *this;
+    }
     const size_t n = std::min(w_.size(), o.w_.size());
     for (size_t i = 0; i < n; ++i) w_[i] &= ~o.w_[i];
     return *this;
 }
 std::vector<DocumentId> DocSet::to_ids() const {
+    if (small_) return ids_;
     std::vector<DocumentId> ids;
     for (size_t i = 0; i < w_.size(); ++i) {
         uint64_t w = w_[i];
@@ -310,8 +378,14 @@ void recursive_sort(size_t current_rule, std::vector<ScoreDetails>& score,
                     std::vector<std::unique_ptr<RankingRule>>& ranking_rule, uint64_t& limit,
                     uint64_t& skip, std::vector<std::pair<DocumentId, std::vector<ScoreDetails>>>& output,
                     DocSet& visited) {
-    while (std::optional<RankingRuleOutput> bucket = ranking_rule[current_rule]->next_bucket()) {
+    for (;;) {
+        // The reference asks its rule for one more bucket before it notices that the limit
+        // is used up (bucket_sort.rs:45-49) and drops it. With VectorSort that extra bucket
+        // is a cache refill, i.e. a second full nns_by_vector per query; asking only while
+        // something can still be returned gives the same output for half the scans.
         if (limit == 0) return;
+        std::optional<RankingRuleOutput> bucket = ranking_rule[current_rule]->next_bucket();
+        if (!bucket) break;
         DocSet& docids = bucket->candidates;
         docids -= visited;
         const uint64_t len = docids.len();
@@ -464,32 +538,40 @@ void VectorSort::fill_buffer(const DocSet& vector_candidates) {
 
 void VectorSort::start_iteration(DocSet candidates) {
     candidates_ = std::move(candidates);
-    const DocSet vector_candidates = vector_candidates_ & candidates_;
-    fill_buffer(vector_candidates);
+    candidates_len_ = candidates_.len();
+    live_ = vector_candidates_ & candidates_;
+    live_len_ = live_.len();
+    fill_buffer(live_);
 }
 
 std::optional<RankingRuleOutput> VectorSort::next_bucket() {
     for (;;) {  // the reference recurses after a refill
-        if (candidates_.is_empty()) return std::nullopt;
-        const DocSet vector_candidates = vector_candidates_ & candidates_;
-        if (vector_candidates.is_empty()) {
+        if (candidates_len_ == 0) return std::nullopt;
+        if (live_len_ == 0) {
+            // Mirrors the reference's assignment order (vector_sort.rs:102-109): the
+            // candidates are cleared first, so the bucket that is returned is empty.
             candidates_ = DocSet();
+            candidates_len_ = 0;
             return RankingRuleOutput{ScoreDetails::vector(std::nullopt), candidates_};
         }
         while (cursor_ < cached_sorted_docids_.size()) {
             const auto [docid, distance] = cached_sorted_docids_[cursor_++];
-            if (vector_candidates.contains(docid)) {
+            if (live_.contains(docid)) {
                 float score = 1.0f - distance;
                 if (distribution_shift_) score = distribution_shift_->shift(score);
                 candidates_.remove(docid);
+                live_.remove(docid);
+                --candidates_len_;
+                --live_len_;
                 return RankingRuleOutput{ScoreDetails::vector(score), DocSet::from_ids({docid})};
             }
         }
         // the cache is exhausted: refill it and run again
-        fill_buffer(vector_candidates);
+        fill_buffer(live_);
         if (cached_sorted_docids_.empty()) {
             // no document with a vector is left in the universe
             candidates_ = DocSet();
+            candidates_len_ = 0;
             return RankingRuleOutput{ScoreDetails::vector(std::nullopt), candidates_};
         }
     }

@@ -49,8 +49,11 @@ struct Error : std::runtime_error {
 
 // ---- docid sets ----------------------------------------------------------------
 
-// Dense bitmap with the handful of RoaringBitmap operations the path uses. Bit
-// (d & 63) of word d >> 6 — the layout vs_search takes as its candidate mask.
+// The handful of RoaringBitmap operations the path uses. Like a roaring bitmap the set has
+// two representations: a sorted array while it is small (a one-document bucket, the documents
+// already returned) and a dense bitmap otherwise -- bit (d & 63) of word d >> 6, the layout
+// vs_search takes as its candidate mask. Operations cost the size of the smaller operand
+// wherever a roaring bitmap's would.
 class DocSet {
    public:
     DocSet() = default;
@@ -66,10 +69,16 @@ class DocSet {
     DocSet& operator|=(const DocSet& o);
     DocSet& operator-=(const DocSet& o);
     std::vector<DocumentId> to_ids() const;  // ascending
-    const std::vector<uint64_t>& words() const { return w_; }
+    // dense words (trailing zero words may be missing); materialised on demand for a small set
+    const std::vector<uint64_t>& words() const;
 
    private:
-    std::vector<uint64_t> w_;
+    static constexpr size_t SMALL_MAX = 4096;  // roaring's array-container limit
+    void densify() const;
+    bool small_ = true;
+    std::vector<DocumentId> ids_;        // small_: ascending, unique
+    mutable std::vector<uint64_t> w_;    // !small_: the bitmap; small_: cache for words()
+    mutable bool w_valid_ = false;       // small_ only
 };
 
 // ---- DistributionShift -----------------------------------------------------------
@@ -206,6 +215,10 @@ class VectorSort : public RankingRule {
     std::vector<float> target_;
     DocSet candidates_;
     DocSet vector_candidates_;
+    // vector_candidates_ & candidates_ (the reference recomputes it in every next_bucket,
+    // vector_sort.rs:100; here it follows candidates_ as documents are removed) and |candidates_|
+    DocSet live_;
+    uint64_t candidates_len_ = 0, live_len_ = 0;
     std::vector<std::pair<DocumentId, float>> cached_sorted_docids_;
     size_t cursor_ = 0;
     size_t limit_;

@@ -361,3 +361,27 @@ def test_bucket_sort_matches_oracle_on_fake_rules():
         got = host().bucket_sort([CountRule(m) for m in mods], limit, skip, universe)
         want = ref.bucket_sort([CountRule(m) for m in mods], limit, skip, universe)
         assert got == want, (mods, limit, skip)
+
+
+def test_docsets_beyond_the_small_array_limit():
+    """More than 4096 documents: the host mirror's docid sets switch from a sorted array to a
+    dense bitmap (as a roaring container does); results stay those of the oracle on either
+    side of the switch and across it."""
+    rng = np.random.default_rng(77)
+    n_docs, dim = 6000, 4
+    stores, py_readers = make_random_world(rng, n_docs, dim, 1)
+    q = rng.standard_normal(dim).astype(np.float32).tolist()
+    all_docids = list(range(n_docs))
+    ctx = FakeContext(stores, all_docids)
+    for universe in (all_docids, all_docids[::2], all_docids[:4096], all_docids[:4097], [5, 4500, 5999]):
+        for skip, limit in ((0, 10), (4, 3), (0, 0)):
+            got = host().execute_vector_search(ctx, q, universe, skip, limit, "manual", None)
+            want = ref.execute_vector_search(py_readers, all_docids, q, universe, skip, limit, None)
+            assert got["documents_ids"] == want["documents_ids"]
+            assert got["candidates"] == want["candidates"]
+    # `visited` grows through the limit while buckets of every size are subtracted from it
+    universe = all_docids[::-1]
+    for limit, skip in ((5000, 0), (4500, 1000), (10, 5990)):
+        got = host().bucket_sort([CountRule(3), CountRule(2)], limit, skip, universe)
+        want = ref.bucket_sort([CountRule(3), CountRule(2)], limit, skip, universe)
+        assert got == want
