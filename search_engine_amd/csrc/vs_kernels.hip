@@ -26,7 +26,7 @@
 namespace vs {
 
 constexpr int WAVES = 4;               // waves per workgroup
-constexpr int QCAP = 64 + 64;          // row queue entries per wave: one mask word + leftovers
+constexpr int QCAP = 128 + 64;         // row queue entries per wave: the largest scoring group + one mask word
 constexpr uint32_t NUM_CUS = 256;       // MI355X
 
 struct ScanArgs {
@@ -629,7 +629,11 @@ hipError_t launch_scan_hamming(const SlabView& s, const void* d_query, const uin
     hipError_t e;
     if (ni <= 1) e = launch_hamming_t<1, 4>(a, blocks, lds, t, stream);
     else if (ni <= 2) e = launch_hamming_t<2, 4>(a, blocks, lds, t, stream);
-    else if (ni <= 3) e = launch_hamming_t<3, 4>(a, blocks, lds, t, stream);
+    else if (ni <= 3) {
+        if (t.rows_in_flight == 2) e = launch_hamming_t<3, 2>(a, blocks, lds, t, stream);
+        else if (t.rows_in_flight == 8) e = launch_hamming_t<3, 8>(a, blocks, lds, t, stream);
+        else e = launch_hamming_t<3, 4>(a, blocks, lds, t, stream);
+    }
     else if (ni <= 4) e = launch_hamming_t<4, 2>(a, blocks, lds, t, stream);
     else if (ni <= 8) e = launch_hamming_t<8, 2>(a, blocks, lds, t, stream);
     else return hipErrorInvalidValue;
