@@ -155,6 +155,24 @@ int32_t vs_search_roaring(vs_store* s, const float* query, uint32_t dim, uint32_
                           const uint8_t* roaring_bytes, size_t len, uint32_t* out_ids,
                           float* out_dist, uint32_t* out_n);
 
+/* A candidate filter kept in device memory for reuse. The reference evaluates
+ * its filter into a RoaringBitmap once per request (`filtered_universe`,
+ * src/search/search.rs:222-228) and passes it to every nns_by_vector call of the
+ * request (src/search/ranking/vector_sort.rs:73-77); a host that sees the same
+ * facet filter again (the next page, the next query under the same facets) can
+ * keep its mask on the device instead of sending N/8 bytes with every search.
+ * A mask belongs to the store it was created for (it is aligned with that
+ * store's docid range) and is immutable: any number of threads may search with
+ * it. Destroy it before the store. Documents removed or added later need no
+ * new mask: a search intersects the mask with the store's sealed state. */
+typedef struct vs_mask vs_mask;
+int32_t vs_mask_create(vs_store* s, const uint64_t* mask_words, uint64_t n_mask_words, vs_mask** out);
+int32_t vs_mask_create_roaring(vs_store* s, const uint8_t* roaring_bytes, size_t len, vs_mask** out);
+int32_t vs_mask_destroy(vs_mask* m);
+/* vs_search with the candidates of `mask` (NULL = every item). */
+int32_t vs_search_mask(vs_store* s, const float* query, uint32_t dim, uint32_t k, const vs_mask* mask,
+                       uint32_t* out_ids, float* out_dist, uint32_t* out_n);
+
 /* `n_q` queries against one shared candidate mask. out_ids / out_dist hold
  * n_q * k entries (query i at offset i * k), out_n holds n_q counts. On a
  * VS_BF16 store with k <= VS_BATCH_MAX_K this runs the batched matrix-core scan

@@ -51,6 +51,10 @@ SIGNATURES = {
     "vs_search": [_vp, _f32p, _u32, _u32, _u64p, _u64, _u32p, _f32p, _u32p],
     "vs_search_roaring": [_vp, _f32p, _u32, _u32, _u8p, _sz, _u32p, _f32p, _u32p],
     "vs_search_batch": [_vp, _f32p, _u32, _u32, _u32, _u64p, _u64, _u32p, _f32p, _u32p],
+    "vs_mask_create": [_vp, _u64p, _u64, ctypes.POINTER(_vp)],
+    "vs_mask_create_roaring": [_vp, _u8p, _sz, ctypes.POINTER(_vp)],
+    "vs_mask_destroy": [_vp],
+    "vs_search_mask": [_vp, _f32p, _u32, _u32, _vp, _u32p, _f32p, _u32p],
     "vs_search_workspace_bytes": [_vp, _u32, _u64p],
     "vs_search_device": [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp],
     "vs_search_batch_workspace_bytes": [_vp, _u32, _u64p],
@@ -247,6 +251,30 @@ class Store:
         self._ck(lib.vs_search_roaring(self.handle, _ptr(query, _f32p), query.size, k, bp,
                                        len(roaring_bytes), _ptr(ids, _u32p), _ptr(dist, _f32p),
                                        ctypes.byref(n)))
+        return ids[: n.value].copy(), dist[: n.value].copy()
+
+    def create_mask(self, mask=None, roaring_bytes=None):
+        """A candidate filter kept on the device (dense words or a serialised RoaringBitmap);
+        returns an opaque handle for search_mask / destroy_mask."""
+        h = _vp()
+        if roaring_bytes is not None:
+            keep, bp = _bytes_ptr(roaring_bytes)
+            self._ck(lib.vs_mask_create_roaring(self.handle, bp, len(roaring_bytes), ctypes.byref(h)))
+        else:
+            mask = np.ascontiguousarray(mask, np.uint64)
+            self._ck(lib.vs_mask_create(self.handle, _ptr(mask, _u64p), mask.size, ctypes.byref(h)))
+        return h
+
+    def destroy_mask(self, handle):
+        self._ck(lib.vs_mask_destroy(handle))
+
+    def search_mask(self, query, k, mask_handle):
+        query = np.ascontiguousarray(query, np.float32)
+        ids = np.zeros(max(k, 1), np.uint32)
+        dist = np.zeros(max(k, 1), np.float32)
+        n = ctypes.c_uint32(0)
+        self._ck(lib.vs_search_mask(self.handle, _ptr(query, _f32p), query.size, k, mask_handle,
+                                    _ptr(ids, _u32p), _ptr(dist, _f32p), ctypes.byref(n)))
         return ids[: n.value].copy(), dist[: n.value].copy()
 
     def search_batch(self, queries, k, mask=None):

@@ -22,31 +22,47 @@ DocSet DocSet::from_ids(const std::vector<DocumentId>& ids) {
         s.ids_.erase(std::unique(s.ids_.begin(), s.ids_.end()), s.ids_.end());
     } else {
         s.small_ = false;
-        for (DocumentId d : ids) s.insert(d);
+        DocumentId top = 0;
+        for (DocumentId d : ids) top = std::max(top, d);
+        s.dense_ = std::make_shared<std::vector<uint64_t>>((size_t)(top >> 6) + 1, 0);
+        for (DocumentId d : ids) (*s.dense_)[d >> 6] |= 1ull << (d & 63);
     }
     return s;
 }
 DocSet DocSet::from_words(std::vector<uint64_t> words) {
     DocSet s;
     s.small_ = false;
-    s.w_ = std::move(words);
+    s.dense_ = std::make_shared<std::vector<uint64_t>>(std::move(words));
     return s;
 }
-void DocSet::densify() const {  // fills w_ from ids_
-    w_.assign(ids_.empty() ? 0 : (size_t)(ids_.back() >> 6) + 1, 0);
-    for (DocumentId d : ids_) w_[d >> 6] |= 1ull << (d & 63);
+static std::shared_ptr<std::vector<uint64_t>> words_of(const std::vector<DocumentId>& ids) {
+    auto w = std::make_shared<std::vector<uint64_t>>(ids.empty() ? 0 : (size_t)(ids.back() >> 6) + 1, 0);
+    for (DocumentId d : ids) (*w)[d >> 6] |= 1ull << (d & 63);
+    return w;
+}
+void DocSet::to_dense() {
+    dense_ = words_of(ids_);
+    small_ = false;
+    ids_.clear();
+    cache_.reset();
+}
+std::vector<uint64_t>& DocSet::own() {
+    if (!dense_) dense_ = std::make_shared<std::vector<uint64_t>>();
+    else if (dense_.use_count() > 1) dense_ = std::make_shared<std::vector<uint64_t>>(*dense_);
+    return *dense_;
 }
 const std::vector<uint64_t>& DocSet::words() const {
-    if (small_ && !w_valid_) {
-        densify();
-        w_valid_ = true;
+    static const std::vector<uint64_t> none;
+    if (small_) {
+        if (!cache_) cache_ = words_of(ids_);
+        return *cache_;
     }
-    return w_;
+    return dense_ ? *dense_ : none;
 }
 bool DocSet::contains(DocumentId d) const {
     if (small_) return std::binary_search(ids_.begin(), ids_.end(), d);
     const size_t wi = d >> 6;
-    return wi < w_.size() && ((w_[wi] >> (d & 63)) & 1);
+    return dense_ && wi < dense_->size() && (((*dense_)[wi] >> (d & 63)) & 1);
 }
 bool DocSet::insert(DocumentId d) {
     if (small_) {
@@ -54,18 +70,17 @@ bool DocSet::insert(DocumentId d) {
         if (it != ids_.end() && *it == d) return false;
         if (ids_.size() < SMALL_MAX) {
             ids_.insert(it, d);
-            w_valid_ = false;
+            cache_.reset();
             return true;
         }
-        densify();
-        small_ = false;
-        ids_.clear();
+        to_dense();
     }
+    std::vector<uint64_t>& w = own();
     const size_t wi = d >> 6;
-    if (wi >= w_.size()) w_.resize(wi + 1, 0);
+    if (wi >= w.size()) w.resize(wi + 1, 0);
     const uint64_t bit = 1ull << (d & 63);
-    const bool fresh = !(w_[wi] & bit);
-    w_[wi] |= bit;
+    const bool fresh = !(w[wi] & bit);
+    w[wi] |= bit;
     return fresh;
 }
 bool DocSet::remove(DocumentId d) {
@@ -73,42 +88,51 @@ bool DocSet::remove(DocumentId d) {
         auto it = std::lower_bound(ids_.begin(), ids_.end(), d);
         if (it == ids_.end() || *it != d) return false;
         ids_.erase(it);
-        w_valid_ = false;
+        cache_.reset();
         return true;
     }
-    const size_t wi = d >> 6;
-    if (wi >= w_.size()) return false;
-    const uint64_t bit = 1ull << (d & 63);
-    const bool had = w_[wi] & bit;
-    w_[wi] &= ~bit;
-    return had;
+    if (!contains(d)) return false;
+    own()[d >> 6] &= ~(1ull << (d & 63));
+    return true;
 }
 uint64_t DocSet::len() const {
     if (small_) return ids_.size();
     uint64_t n = 0;
-    for (uint64_t w : w_) n += (uint64_t)__builtin_popcountll(w);
+    if (dense_)
+        for (uint64_t w : *dense_) n += (uint64_t)__builtin_popcountll(w);
     return n;
 }
 bool DocSet::is_empty() const {
     if (small_) return ids_.empty();
-    for (uint64_t w : w_)
-        if (w) return false;
+    if (dense_)
+        for (uint64_t w : *dense_)
+            if (w) return false;
     return true;
 }
-DocSet DocSet::operator&(const DocSet& o) const {
+DocSet DocSet::intersect(const DocSet& o, uint64_t* len) const {
     DocSet r;
     if (small_ || o.small_) {  // walk the small one, probe the other
         const DocSet& a = small_ ? *this : o;
         const DocSet& b = small_ ? o : *this;
         for (DocumentId d : a.ids_)
             if (b.contains(d)) r.ids_.push_back(d);
+        if (len) *len = r.ids_.size();
         return r;
     }
     r.small_ = false;
-    r.w_.resize(std::min(w_.size(), o.w_.size()));
-    for (size_t i = 0; i < r.w_.size(); ++i) r.w_[i] = w_[i] & o.w_[i];
+    const std::vector<uint64_t>& x = words();
+    const std::vector<uint64_t>& y = o.words();
+    r.dense_ = std::make_shared<std::vector<uint64_t>>(std::min(x.size(), y.size()));
+    uint64_t n = 0;
+    for (size_t i = 0; i < r.dense_->size(); ++i) {
+        const uint64_t w = x[i] & y[i];
+        (*r.dense_)[i] = w;
+        n += (uint64_t)__builtin_popcountll(w);
+    }
+    if (len) *len = n;
     return r;
 }
+DocSet DocSet::operator&(const DocSet& o) const { return intersect(o, nullptr); }
 DocSet DocSet::operator|(const DocSet& o) const {
     DocSet r = *this;
     r |= o;
@@ -119,34 +143,35 @@ DocSet& DocSet::operator|=(const DocSet& o) {
         for (DocumentId d : o.ids_) insert(d);
         return *this;
     }
-    if (small_) {  // becomes dense
-        densify();
-        small_ = false;
-        ids_.clear();
-    }
-    if (o.w_.size() > w_.size()) w_.resize(o.w_.size(), 0);
-    for (size_t i = 0; i < o.w_.size(); ++i) w_[i] |= o.w_[i];
+    if (small_) to_dense();
+    std::vector<uint64_t>& w = own();
+    const std::vector<uint64_t>& y = o.words();
+    if (y.size() > w.size()) w.resize(y.size(), 0);
+    for (size_t i = 0; i < y.size(); ++i) w[i] |= y[i];
     return *this;
 }
 DocSet& DocSet::operator-=(const DocSet& o) {
     if (small_) {
         ids_.erase(std::remove_if(ids_.begin(), ids_.end(), [&](DocumentId d) { return o.contains(d); }), ids_.end());
-        w_valid_ = false;
+        cache_.reset();
         return *this;
     }
     if (o.small_) {
         for (DocumentId d : o.ids_) remove(d);
         return *this;
     }
-    const size_t n = std::min(w_.size(), o.w_.size());
-    for (size_t i = 0; i < n; ++i) w_[i] &= ~o.w_[i];
+    std::vector<uint64_t>& w = own();
+    const std::vector<uint64_t>& y = o.words();
+    const size_t n = std::min(w.size(), y.size());
+    for (size_t i = 0; i < n; ++i) w[i] &= ~y[i];
     return *this;
 }
 std::vector<DocumentId> DocSet::to_ids() const {
     if (small_) return ids_;
     std::vector<DocumentId> ids;
-    for (size_t i = 0; i < w_.size(); ++i) {
-        uint64_t w = w_[i];
+    const std::vector<uint64_t>& x = words();
+    for (size_t i = 0; i < x.size(); ++i) {
+        uint64_t w = x[i];
         while (w) {
             ids.push_back((DocumentId)(i * 64 + (size_t)__builtin_ctzll(w)));
             w &= w - 1;
@@ -537,10 +562,8 @@ void VectorSort::fill_buffer(const DocSet& vector_candidates) {
 }
 
 void VectorSort::start_iteration(DocSet candidates) {
-    candidates_ = std::move(candidates);
-    candidates_len_ = candidates_.len();
-    live_ = vector_candidates_ & candidates_;
-    live_len_ = live_.len();
+    candidates_len_ = candidates.len();
+    live_ = vector_candidates_.intersect(candidates, &live_len_);
     fill_buffer(live_);
 }
 
@@ -550,16 +573,14 @@ std::optional<RankingRuleOutput> VectorSort::next_bucket() {
         if (live_len_ == 0) {
             // Mirrors the reference's assignment order (vector_sort.rs:102-109): the
             // candidates are cleared first, so the bucket that is returned is empty.
-            candidates_ = DocSet();
             candidates_len_ = 0;
-            return RankingRuleOutput{ScoreDetails::vector(std::nullopt), candidates_};
+            return RankingRuleOutput{ScoreDetails::vector(std::nullopt), DocSet()};
         }
         while (cursor_ < cached_sorted_docids_.size()) {
             const auto [docid, distance] = cached_sorted_docids_[cursor_++];
             if (live_.contains(docid)) {
                 float score = 1.0f - distance;
                 if (distribution_shift_) score = distribution_shift_->shift(score);
-                candidates_.remove(docid);
                 live_.remove(docid);
                 --candidates_len_;
                 --live_len_;
@@ -570,9 +591,8 @@ std::optional<RankingRuleOutput> VectorSort::next_bucket() {
         fill_buffer(live_);
         if (cached_sorted_docids_.empty()) {
             // no document with a vector is left in the universe
-            candidates_ = DocSet();
             candidates_len_ = 0;
-            return RankingRuleOutput{ScoreDetails::vector(std::nullopt), candidates_};
+            return RankingRuleOutput{ScoreDetails::vector(std::nullopt), DocSet()};
         }
     }
 }

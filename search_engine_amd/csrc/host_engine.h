@@ -53,7 +53,8 @@ struct Error : std::runtime_error {
 // two representations: a sorted array while it is small (a one-document bucket, the documents
 // already returned) and a dense bitmap otherwise -- bit (d & 63) of word d >> 6, the layout
 // vs_search takes as its candidate mask. Operations cost the size of the smaller operand
-// wherever a roaring bitmap's would.
+// wherever a roaring bitmap's would; copies of a dense set share its words until one of them
+// is modified.
 class DocSet {
    public:
     DocSet() = default;
@@ -65,6 +66,8 @@ class DocSet {
     uint64_t len() const;
     bool is_empty() const;
     DocSet operator&(const DocSet& o) const;
+    // *this & o, and its cardinality, in one pass
+    DocSet intersect(const DocSet& o, uint64_t* len) const;
     DocSet operator|(const DocSet& o) const;
     DocSet& operator|=(const DocSet& o);
     DocSet& operator-=(const DocSet& o);
@@ -74,11 +77,12 @@ class DocSet {
 
    private:
     static constexpr size_t SMALL_MAX = 4096;  // roaring's array-container limit
-    void densify() const;
+    void to_dense();                           // small_ -> dense
+    std::vector<uint64_t>& own();              // the dense words, unshared
     bool small_ = true;
-    std::vector<DocumentId> ids_;        // small_: ascending, unique
-    mutable std::vector<uint64_t> w_;    // !small_: the bitmap; small_: cache for words()
-    mutable bool w_valid_ = false;       // small_ only
+    std::vector<DocumentId> ids_;                           // small_: ascending, unique
+    std::shared_ptr<std::vector<uint64_t>> dense_;          // !small_: the bitmap, shared between copies
+    mutable std::shared_ptr<std::vector<uint64_t>> cache_;  // small_: what words() last built
 };
 
 // ---- DistributionShift -----------------------------------------------------------
@@ -213,10 +217,10 @@ class VectorSort : public RankingRule {
     void fill_buffer(const DocSet& vector_candidates);
     Context& ctx_;
     std::vector<float> target_;
-    DocSet candidates_;
     DocSet vector_candidates_;
-    // vector_candidates_ & candidates_ (the reference recomputes it in every next_bucket,
-    // vector_sort.rs:100; here it follows candidates_ as documents are removed) and |candidates_|
+    // The reference keeps `candidates`, removes every emitted document from it and recomputes
+    // vector_candidates & candidates in every next_bucket (vector_sort.rs:100,118). Only that
+    // intersection and the two cardinalities are ever looked at, so they are what is kept.
     DocSet live_;
     uint64_t candidates_len_ = 0, live_len_ = 0;
     std::vector<std::pair<DocumentId, float>> cached_sorted_docids_;

@@ -96,6 +96,11 @@ struct vs_ctx {
     hipStream_t upload_stream = nullptr;
 };
 
+struct vs_mask {
+    vs_store* store;
+    uint64_t* d_words;  // store->n_slots / 64 words, aligned with the store
+};
+
 struct vs_store {
     vs_ctx* ctx = nullptr;
     uint16_t index = 0;
@@ -307,6 +312,23 @@ int32_t stage_dense_mask(vs_store* s, Workspace* ws, const uint64_t* mask_words,
                                ws->stream));
     if (ncopy < n_words)
         HIP_TRY(hipMemsetAsync(ws->d_mask + ncopy, 0, (size_t)(n_words - ncopy) * 8, ws->stream));
+    return VS_OK;
+}
+
+// Expands a parsed serialised RoaringBitmap into `d_words` (n_slots / 64 words aligned with the store).
+int32_t expand_roaring(vs_store* s, Workspace* ws, const uint8_t* roaring_bytes, size_t len,
+                       const std::vector<vs::RoaringContainerDesc>& desc, uint64_t* d_words) {
+    const uint64_t n_words = s->n_slots / 64;
+    HIP_TRY(hipMemsetAsync(d_words, 0, (size_t)n_words * 8, ws->stream));
+    if (desc.empty()) return VS_OK;
+    const size_t blob = (len + 15) / 16 * 16;
+    const size_t desc_b = desc.size() * sizeof(vs::RoaringContainerDesc);
+    if (int32_t rc = grow(&ws->d_blob, &ws->blob_bytes, blob + desc_b)) return rc;
+    HIP_TRY(hipMemcpyAsync(ws->d_blob, roaring_bytes, len, hipMemcpyHostToDevice, ws->stream));
+    HIP_TRY(hipMemcpyAsync(ws->d_blob + blob, desc.data(), desc_b, hipMemcpyHostToDevice, ws->stream));
+    HIP_TRY(vs::launch_roaring_expand(ws->d_blob,
+                                      reinterpret_cast<const vs::RoaringContainerDesc*>(ws->d_blob + blob),
+                                      (uint32_t)desc.size(), s->docid_base, d_words, n_words, ws->stream));
     return VS_OK;
 }
 
@@ -663,21 +685,102 @@ extern "C" int32_t vs_search_roaring(vs_store* s, const float* query, uint32_t d
     auto body = [&]() -> int32_t {
         const uint64_t n_words = s->n_slots / 64;
         if (int32_t rc = grow(&ws->d_mask, &ws->mask_words, (size_t)n_words * 8)) return rc;
-        HIP_TRY(hipMemsetAsync(ws->d_mask, 0, (size_t)n_words * 8, ws->stream));
-        if (!desc.empty()) {
-            const size_t blob = (len + 15) / 16 * 16;
-            const size_t desc_b = desc.size() * sizeof(vs::RoaringContainerDesc);
-            if (int32_t rc = grow(&ws->d_blob, &ws->blob_bytes, blob + desc_b)) return rc;
-            HIP_TRY(hipMemcpyAsync(ws->d_blob, roaring_bytes, len, hipMemcpyHostToDevice, ws->stream));
-            HIP_TRY(hipMemcpyAsync(ws->d_blob + blob, desc.data(), desc_b, hipMemcpyHostToDevice,
-                                   ws->stream));
-            HIP_TRY(vs::launch_roaring_expand(
-                ws->d_blob, reinterpret_cast<const vs::RoaringContainerDesc*>(ws->d_blob + blob),
-                (uint32_t)desc.size(), s->docid_base, ws->d_mask, n_words, ws->stream));
-        }
+        if (int32_t rc = expand_roaring(s, ws.get(), roaring_bytes, len, desc, ws->d_mask)) return rc;
         return run_and_fetch(s, ws.get(), query, k, ws->d_mask, out_ids, out_dist, out_n);
     };
     const int32_t rc = body();
+    ws_release(s->ctx, std::move(ws));
+    return rc;
+}
+
+// ---- candidate masks kept on the device ------------------------------------------------------
+
+namespace {
+int32_t mask_new(vs_store* s, vs_mask** out, std::unique_ptr<vs_mask>* m) {
+    if (!out) return fail(VS_E_INVALID_ARG, "null out pointer");
+    *out = nullptr;
+    if (int32_t rc = check_store(s)) return rc;
+    m->reset(new vs_mask{s, nullptr});
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    if (hipMalloc(&(*m)->d_words, (size_t)(s->n_slots / 64) * 8) != hipSuccess)
+        return fail(VS_E_OOM, "cannot allocate a %llu-byte mask", (unsigned long long)(s->n_slots / 8));
+    return VS_OK;
+}
+}  // namespace
+
+extern "C" int32_t vs_mask_create(vs_store* s, const uint64_t* mask_words, uint64_t n_mask_words,
+                                  vs_mask** out) {
+    std::unique_ptr<vs_mask> m;
+    if (int32_t rc = mask_new(s, out, &m)) return rc;
+    if (!mask_words && n_mask_words) {
+        (void)hipFree(m->d_words);
+        return fail(VS_E_INVALID_ARG, "null mask words");
+    }
+    std::unique_ptr<Workspace> ws;
+    int32_t rc = ws_acquire(s->ctx, &ws);
+    if (rc == VS_OK) {
+        // stage through the workspace's routine, then keep the words
+        rc = stage_dense_mask(s, ws.get(), mask_words, n_mask_words);
+        if (rc == VS_OK) {
+            rc = [&]() -> int32_t {
+                HIP_TRY(hipMemcpyAsync(m->d_words, ws->d_mask, (size_t)(s->n_slots / 64) * 8,
+                                       hipMemcpyDeviceToDevice, ws->stream));
+                HIP_TRY(hipStreamSynchronize(ws->stream));
+                return VS_OK;
+            }();
+        }
+        ws_release(s->ctx, std::move(ws));
+    }
+    if (rc != VS_OK) {
+        (void)hipFree(m->d_words);
+        return rc;
+    }
+    *out = m.release();
+    return VS_OK;
+}
+
+extern "C" int32_t vs_mask_create_roaring(vs_store* s, const uint8_t* roaring_bytes, size_t len,
+                                          vs_mask** out) {
+    if (out) *out = nullptr;
+    if (!roaring_bytes) return fail(VS_E_INVALID_ARG, "null roaring bytes");
+    std::vector<vs::RoaringContainerDesc> desc;
+    if (!vs::roaring_parse(roaring_bytes, len, &desc))
+        return fail(VS_E_FORMAT, "malformed serialised RoaringBitmap (%zu bytes)", len);
+    std::unique_ptr<vs_mask> m;
+    if (int32_t rc = mask_new(s, out, &m)) return rc;
+    std::unique_ptr<Workspace> ws;
+    int32_t rc = ws_acquire(s->ctx, &ws);
+    if (rc == VS_OK) {
+        rc = expand_roaring(s, ws.get(), roaring_bytes, len, desc, m->d_words);
+        if (rc == VS_OK && hipStreamSynchronize(ws->stream) != hipSuccess)
+            rc = fail(VS_E_DEVICE, "mask expansion failed");
+        ws_release(s->ctx, std::move(ws));
+    }
+    if (rc != VS_OK) {
+        (void)hipFree(m->d_words);
+        return rc;
+    }
+    *out = m.release();
+    return VS_OK;
+}
+
+extern "C" int32_t vs_mask_destroy(vs_mask* m) {
+    if (!m) return VS_OK;
+    (void)hipFree(m->d_words);
+    delete m;
+    return VS_OK;
+}
+
+extern "C" int32_t vs_search_mask(vs_store* s, const float* query, uint32_t dim, uint32_t k,
+                                  const vs_mask* mask, uint32_t* out_ids, float* out_dist,
+                                  uint32_t* out_n) {
+    if (int32_t rc = begin_search(s, query, dim, k, out_ids, out_dist, out_n)) return rc;
+    *out_n = 0;
+    if (mask && mask->store != s) return fail(VS_E_INVALID_ARG, "the mask was created for another store");
+    if (k == 0) return VS_OK;
+    std::unique_ptr<Workspace> ws;
+    if (int32_t rc = ws_acquire(s->ctx, &ws)) return rc;
+    const int32_t rc = run_and_fetch(s, ws.get(), query, k, mask ? mask->d_words : nullptr, out_ids, out_dist, out_n);
     ws_release(s->ctx, std::move(ws));
     return rc;
 }

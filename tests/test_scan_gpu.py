@@ -327,6 +327,54 @@ def test_search_batch_and_roaring(gpu_ctx):
         store.destroy()
 
 
+def test_masks_kept_on_the_device(gpu_ctx):
+    """vs_mask_*: a filter uploaded once (dense words or serialised roaring) gives the results of
+    vs_search with the same filter, for every query, before and after the store changes."""
+    from search_engine_amd import abi
+    dim, base = 96, 64 * 50
+    rng = np.random.default_rng(3)
+    docids = np.sort(rng.choice(40000, 9000, replace=False)).astype(np.uint32) + base
+    vectors = synthetic_vectors(docids.size, dim, 93)
+    queries = synthetic_vectors(6, dim, 94)
+    mask = facet_mask(base + 40000 + 500, 10)  # longer than the store: the tail is ignored
+    store = make_store(gpu_ctx, vectors, docids, capacity=40000, docid_base=base)
+    other = make_store(gpu_ctx, vectors[:100])
+    handles = []
+    try:
+        handles = [store.create_mask(mask), store.create_mask(roaring_bytes=abi.mask_to_roaring(mask)),
+                   store.create_mask(mask[: base // 64 + 100]),  # shorter than the store: the rest is no candidate
+                   store.create_mask(np.zeros(0, np.uint64))]
+        short = mask.copy()
+        short[base // 64 + 100:] = 0
+        for q in queries:
+            want = store.search(q, 15, mask)
+            for h in handles[:2]:
+                got = store.search_mask(q, 15, h)
+                assert got[0].tolist() == want[0].tolist() and got[1].tolist() == want[1].tolist()
+            got, want_short = store.search_mask(q, 15, handles[2]), store.search(q, 15, short)
+            assert got[0].tolist() == want_short[0].tolist()
+            assert store.search_mask(q, 15, handles[3])[0].size == 0
+            none = store.search_mask(q, 15, None)  # NULL = every item
+            assert none[0].tolist() == store.search(q, 15)[0].tolist()
+        # the mask is a set of docids: after a removal + seal it still applies
+        gone = store.search(queries[0], 5, mask)[0]
+        store.remove(gone)
+        store.seal()
+        got, want = store.search_mask(queries[0], 15, handles[0]), store.search(queries[0], 15, mask)
+        assert got[0].tolist() == want[0].tolist() and not set(got[0].tolist()) & set(gone.tolist())
+        with pytest.raises(abi.VsError) as e:
+            other.search_mask(synthetic_vectors(1, dim, 1)[0], 5, handles[0])
+        assert e.value.code == abi.VS_E_INVALID_ARG
+        with pytest.raises(abi.VsError) as e:
+            store.create_mask(roaring_bytes=b"\x01\x02\x03")
+        assert e.value.code == abi.VS_E_FORMAT
+    finally:
+        for h in handles:
+            store.destroy_mask(h)
+        store.destroy()
+        other.destroy()
+
+
 def test_device_api_and_shard_merge(gpu_ctx):
     """Two docid-range shards searched through the device entry point, keys
     concatenated as an all-gather would, merged: identical to one store."""
