@@ -102,6 +102,8 @@ def test_batch_parity_beyond_the_sample_pass(gpu_ctx, pass_percent, k):
             vectors[pos] = queries[j] * (1.0 + 0.01 * rng.standard_normal()) + 0.05 * rng.standard_normal(dim).astype(np.float32)
     vectors[n - 1] = queries[0]
     vectors[70000] = 0.0          # zero-norm row in the bounded pass
+    vectors[100000, 0] = np.inf   # non-finite rows: their tile takes the chunked walk; NaN distances sort last
+    vectors[100300, 3] = np.nan
     queries[5] = 0.0              # zero query: first k candidate docids
     mask = None if pass_percent is None else facet_mask(n, pass_percent)
     store = make_bf16_store(gpu_ctx, vectors)
