@@ -503,11 +503,51 @@ class GpuReader : public Reader {
         return out;
     }
 
+    std::vector<std::vector<std::pair<DocumentId, float>>> nns_by_vectors(
+        const std::vector<std::vector<float>>& targets, size_t count, const DocSet& candidates) override {
+        std::vector<std::vector<std::pair<DocumentId, float>>> out(targets.size());
+        if (targets.empty()) return out;
+        if (count > VS_MAX_K)
+            throw Error(Error::ArroyError, "limit " + std::to_string(count) + " exceeds VS_MAX_K");
+        const size_t dim = targets[0].size(), n_q = targets.size(), kk = count ? count : 1;
+        std::vector<float> flat(n_q * dim);
+        for (size_t i = 0; i < n_q; ++i) {
+            if (targets[i].size() != dim)  // one call needs one dimension; let the single path report it
+                return Reader::nns_by_vectors(targets, count, candidates);
+            std::copy(targets[i].begin(), targets[i].end(), flat.begin() + i * dim);
+        }
+        std::vector<uint32_t> ids(n_q * kk), n(n_q, 0);
+        std::vector<float> dist(n_q * kk);
+        static const uint64_t none = 0;
+        const std::vector<uint64_t>& w = candidates.words();
+        const int32_t rc = vs_search_batch(store_, flat.data(), (uint32_t)n_q, (uint32_t)dim, (uint32_t)count,
+                                           w.empty() ? &none : w.data(), w.size(), ids.data(), dist.data(), n.data());
+        if (rc == VS_E_DIM_MISMATCH) {
+            uint32_t e = 0, r = 0;
+            vs_last_dim_mismatch(ctx_, &e, &r);
+            throw Error(Error::InvalidVectorDimensions,
+                        "Invalid vector dimensions: expected: `" + std::to_string(e) + "`, found: `" +
+                            std::to_string(r) + "`.",
+                        e, r);
+        }
+        if (rc != VS_OK) throw Error(Error::ArroyError, last_error(ctx_));
+        for (size_t i = 0; i < n_q; ++i)
+            for (uint32_t j = 0; j < n[i]; ++j) out[i].emplace_back(ids[i * count + j], dist[i * count + j]);
+        return out;
+    }
+
    private:
     vs_ctx* ctx_;
     vs_store* store_;
 };
 }  // namespace
+
+std::vector<std::vector<std::pair<DocumentId, float>>> Reader::nns_by_vectors(
+    const std::vector<std::vector<float>>& targets, size_t count, const DocSet& candidates) {
+    std::vector<std::vector<std::pair<DocumentId, float>>> out;
+    for (const auto& t : targets) out.push_back(nns_by_vector(t, count, candidates));
+    return out;
+}
 
 uint8_t GpuContext::embedder_category_id(const std::string& name) {
     auto it = ids_.find(name);
@@ -534,19 +574,20 @@ VectorSort::VectorSort(Context& ctx, std::vector<float> target, DocSet vector_ca
       distribution_shift_(distribution),
       embedder_index_(ctx.embedder_category_id(embedder_name)) {}
 
-void VectorSort::fill_buffer(const DocSet& vector_candidates) {
-    const uint16_t writer_index = (uint16_t)((uint16_t)embedder_index_ << 8);
+std::vector<std::unique_ptr<Reader>> VectorSort::open_readers(Context& ctx, uint8_t embedder_index) {
+    const uint16_t writer_index = (uint16_t)((uint16_t)embedder_index << 8);
     std::vector<std::unique_ptr<Reader>> readers;
     for (uint32_t k = 0; k <= 0xFF; ++k) {
-        std::unique_ptr<Reader> reader = ctx_.vector_reader((uint16_t)(writer_index | k));
+        std::unique_ptr<Reader> reader = ctx.vector_reader((uint16_t)(writer_index | k));
         if (!reader) break;  // MissingMetadata ends the map_while
         readers.push_back(std::move(reader));
     }
+    return readers;
+}
+
+void VectorSort::set_cache(std::vector<std::vector<std::pair<DocumentId, float>>> per_store_results) {
     std::vector<std::pair<DocumentId, float>> results;
-    for (auto& reader : readers) {
-        auto nns = reader->nns_by_vector(target_, limit_, vector_candidates);
-        results.insert(results.end(), nns.begin(), nns.end());
-    }
+    for (auto& nns : per_store_results) results.insert(results.end(), nns.begin(), nns.end());
     // The reference sorts by distance alone with an unstable sort, so the order
     // of equal distances from different stores is unspecified there; here it is
     // fixed as (distance, docid, store order), which a stable sort on
@@ -559,6 +600,23 @@ void VectorSort::fill_buffer(const DocSet& vector_candidates) {
     });
     cached_sorted_docids_ = std::move(results);
     cursor_ = 0;
+}
+
+void VectorSort::fill_buffer(const DocSet& vector_candidates) {
+    if (preloaded_) {  // the first fill was computed for this rule together with other queries'
+        auto r = std::move(*preloaded_);
+        preloaded_.reset();
+        set_cache(std::move(r));
+        return;
+    }
+    std::vector<std::vector<std::pair<DocumentId, float>>> per_store;
+    for (auto& reader : open_readers(ctx_, embedder_index_))
+        per_store.push_back(reader->nns_by_vector(target_, limit_, vector_candidates));
+    set_cache(std::move(per_store));
+}
+
+void VectorSort::preload(std::vector<std::vector<std::pair<DocumentId, float>>> per_store_results) {
+    preloaded_ = std::move(per_store_results);
 }
 
 void VectorSort::start_iteration(DocSet candidates) {
@@ -615,6 +673,39 @@ SearchResult execute_vector_search(Context& ctx, const std::vector<float>& vecto
     res.documents_ids = std::move(out.docids);
     res.document_scores = std::move(out.scores);
     return res;
+}
+
+std::vector<SearchResult> execute_vector_search_batch(Context& ctx, const std::vector<std::vector<float>>& vectors,
+                                                      DocSet universe, uint64_t skip, uint64_t limit,
+                                                      const std::string& embedder_name,
+                                                      std::optional<DistributionShift> distribution,
+                                                      const ExtraRules& extra_rules) {
+    // what every query's VectorSort asks its stores first: the nearest skip + limit items of
+    // all_docids & universe (ranking_rule.rs:85, vector_sort.rs:90-93)
+    const uint8_t embedder_index = ctx.embedder_category_id(embedder_name);
+    const DocSet all = ctx.all_docids();
+    const DocSet first_candidates = all & universe;
+    std::vector<std::vector<std::vector<std::pair<DocumentId, float>>>> per_query(vectors.size());
+    for (auto& reader : VectorSort::open_readers(ctx, embedder_index)) {
+        auto r = reader->nns_by_vectors(vectors, (size_t)(skip + limit), first_candidates);
+        for (size_t i = 0; i < vectors.size(); ++i) per_query[i].push_back(std::move(r[i]));
+    }
+    std::vector<SearchResult> out;
+    for (size_t i = 0; i < vectors.size(); ++i) {
+        std::vector<std::unique_ptr<RankingRule>> ranking_rules;
+        auto* vs = new VectorSort(ctx, vectors[i], all, (size_t)(skip + limit), embedder_name, distribution);
+        vs->preload(std::move(per_query[i]));
+        ranking_rules.emplace_back(vs);
+        if (extra_rules)
+            for (auto& r : extra_rules()) ranking_rules.push_back(std::move(r));
+        BucketSortOutput b = bucket_sort(ranking_rules, limit, skip, universe);
+        SearchResult res;
+        res.candidates = std::move(b.candidates);
+        res.documents_ids = std::move(b.docids);
+        res.document_scores = std::move(b.scores);
+        out.push_back(std::move(res));
+    }
+    return out;
 }
 
 // ---- hybrid (src/search/hybrid.rs) ------------------------------------------------------------------------------

@@ -178,6 +178,11 @@ struct Reader {
     virtual std::vector<std::pair<DocumentId, float>> nns_by_vector(const std::vector<float>& target,
                                                                     size_t count,
                                                                     const DocSet& candidates) = 0;
+    // The same for several targets that share `candidates`; result i belongs to targets[i].
+    // No counterpart in arroy: the default is the loop a caller would write, a reader that can
+    // do better (one pass over the store for all targets) overrides it.
+    virtual std::vector<std::vector<std::pair<DocumentId, float>>> nns_by_vectors(
+        const std::vector<std::vector<float>>& targets, size_t count, const DocSet& candidates);
 };
 
 // The methods of `trait Context` the vector path calls.
@@ -212,9 +217,16 @@ class VectorSort : public RankingRule {
                const std::string& embedder_name, std::optional<DistributionShift> distribution);
     void start_iteration(DocSet candidates) override;
     std::optional<RankingRuleOutput> next_bucket() override;
+    // Hands the rule the per-store results of its FIRST fill_buffer (computed elsewhere, for
+    // vector_candidates & the candidates it will be started with), store k at index k.
+    void preload(std::vector<std::vector<std::pair<DocumentId, float>>> per_store_results);
+    // every store (embedder_index << 8) | k of the embedder, k = 0.. until one is missing
+    static std::vector<std::unique_ptr<Reader>> open_readers(Context& ctx, uint8_t embedder_index);
 
    private:
     void fill_buffer(const DocSet& vector_candidates);
+    void set_cache(std::vector<std::vector<std::pair<DocumentId, float>>> per_store_results);
+    std::optional<std::vector<std::vector<std::pair<DocumentId, float>>>> preloaded_;
     Context& ctx_;
     std::vector<float> target_;
     DocSet vector_candidates_;
@@ -246,6 +258,16 @@ SearchResult execute_vector_search(Context& ctx, const std::vector<float>& vecto
                                    uint64_t skip, uint64_t limit, const std::string& embedder_name,
                                    std::optional<DistributionShift> distribution,
                                    const ExtraRules& extra_rules = nullptr);
+
+// execute_vector_search for several vectors under one universe: result i is what
+// execute_vector_search(ctx, vectors[i], universe, ...) returns. The reference has no
+// multi-query Search (src/search/mod.rs:132-179 takes one vector); this is the entry point
+// such a Search would call. Each store is asked once for all vectors (Reader::nns_by_vectors).
+std::vector<SearchResult> execute_vector_search_batch(Context& ctx, const std::vector<std::vector<float>>& vectors,
+                                                      DocSet universe, uint64_t skip, uint64_t limit,
+                                                      const std::string& embedder_name,
+                                                      std::optional<DistributionShift> distribution,
+                                                      const ExtraRules& extra_rules = nullptr);
 
 // ---- hybrid ------------------------------------------------------------------------------------------------
 

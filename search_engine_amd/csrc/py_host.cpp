@@ -350,4 +350,17 @@ PYBIND11_MODULE(_host, m) {
           py::arg("ctx"), py::arg("vector"), py::arg("universe"), py::arg("skip"), py::arg("limit"),
           py::arg("embedder_name"), py::arg("distribution") = py::none(),
           py::arg("extra_rules") = py::none());
+
+    m.def("execute_vector_search_batch",
+          [](py::object ctx, std::vector<std::vector<float>> vectors, py::object universe, uint64_t skip,
+             uint64_t limit, const std::string& embedder_name, py::object distribution) {
+              std::shared_ptr<Context> c = context_from_py(ctx);
+              py::list out;
+              for (const SearchResult& r : execute_vector_search_batch(*c, vectors, to_docset(universe), skip, limit,
+                                                                       embedder_name, distribution_from_py(distribution)))
+                  out.append(result_to_py(r));
+              return out;
+          },
+          py::arg("ctx"), py::arg("vectors"), py::arg("universe"), py::arg("skip"), py::arg("limit"),
+          py::arg("embedder_name"), py::arg("distribution") = py::none());
 }

@@ -70,6 +70,45 @@ def test_vector_search_plumbing_10k_384(gpu_ctx):
             s.destroy()
 
 
+def test_vector_search_batch_plumbing(gpu_ctx):
+    """execute_vector_search_batch through GpuContext: every store is asked once for all vectors
+    (vs_search_batch). f32 stores: identical to the single searches. bf16 stores (batched scan on
+    the matrix cores, queries rounded to bf16): the oracle's result for the rounded inputs."""
+    from search_engine_amd import _host, abi
+    n_docs, dim, n_stores = 6000, 128, 2
+    stores, readers = build_world(gpu_ctx, n_docs, dim, n_stores, 8, (CATEGORY + 2) << 8)
+    bf = []
+    try:
+        ctx = _host.GpuContext(gpu_ctx.handle.value, {"default": CATEGORY + 2, "half": CATEGORY + 3},
+                               oracle.bool_to_mask(np.ones(n_docs, bool)))
+        universe_mask = facet_mask(n_docs, 50)
+        queries = synthetic_vectors(9, dim, 333)
+        for skip, limit, dist in ((0, 10, None), (3, 7, (0.5, 0.2))):
+            got = _host.execute_vector_search_batch(ctx, queries.tolist(), universe_mask, skip, limit, "default", dist)
+            for q, g in zip(queries, got):
+                assert g == _host.execute_vector_search(ctx, q.tolist(), universe_mask, skip, limit, "default", dist)
+        with pytest.raises(_host.HostError) as e:
+            _host.execute_vector_search_batch(ctx, queries[:, :100].tolist(), universe_mask, 0, 10, "default", None)
+        assert e.value.args[1:] == ("InvalidVectorDimensions", dim, 100)
+        # one bf16 store under a second embedder
+        vectors = synthetic_vectors(n_docs, dim, 444)
+        s = gpu_ctx.create_store((CATEGORY + 3) << 8, dim, n_docs, dtype=abi.VS_BF16)
+        s.upload(np.arange(n_docs, dtype=np.uint32), vectors)
+        s.seal()
+        bf.append(s)
+        got = _host.execute_vector_search_batch(ctx, queries.tolist(), universe_mask, 0, 10, "half", None)
+        rv, rq = oracle.bf16_round(vectors), oracle.bf16_round(queries)
+        for q, g in zip(rq, got):
+            want, _ = oracle.nns_by_vector(rv, q, 10, mask=universe_mask)
+            d64 = oracle.all_distances_f64(rv, q)
+            assert len(g["documents_ids"]) == 10
+            for a, b in zip(g["documents_ids"], want.tolist()):  # ids equal unless the two are closer than the tolerance
+                assert a == b or abs(d64[a] - d64[b]) <= 2e-5 * abs(d64[b]) + 2e-6
+    finally:
+        for s in stores + bf:
+            s.destroy()
+
+
 def test_hybrid_plumbing(gpu_ctx):
     """semanticRatio 0.5 with a stubbed keyword list: the vector half comes from the GPU."""
     from search_engine_amd import _host

@@ -385,3 +385,24 @@ def test_docsets_beyond_the_small_array_limit():
         got = host().bucket_sort([CountRule(3), CountRule(2)], limit, skip, universe)
         want = ref.bucket_sort([CountRule(3), CountRule(2)], limit, skip, universe)
         assert got == want
+
+
+def test_execute_vector_search_batch_equals_single_searches():
+    """One universe, several vectors: result i is execute_vector_search of vector i (stores are
+    asked once for all vectors; the fake readers take the default path, a loop)."""
+    rng = np.random.default_rng(11)
+    n_docs, dim, n_stores = 80, 6, 3
+    stores, _ = make_random_world(rng, n_docs, dim, n_stores)
+    all_docids = list(range(n_docs))
+    ctx = FakeContext(stores, all_docids)
+    vectors = rng.standard_normal((7, dim)).astype(np.float32).tolist()
+    for universe in (all_docids, [d for d in all_docids if d % 4 != 1], [3], []):
+        for skip, limit, dist in ((0, 10, None), (4, 6, (0.6, 0.2)), (0, 0, None), (0, 200, None)):
+            got = host().execute_vector_search_batch(ctx, vectors, universe, skip, limit, "manual", dist)
+            assert len(got) == len(vectors)
+            for v, g in zip(vectors, got):
+                assert g == host().execute_vector_search(ctx, v, universe, skip, limit, "manual", dist)
+    assert host().execute_vector_search_batch(ctx, [], all_docids, 0, 5, "manual", None) == []
+    with pytest.raises(host().HostError) as e:
+        host().execute_vector_search_batch(ctx, vectors, all_docids, 0, 5, "nope", None)
+    assert e.value.args[1] == "InvalidEmbedder"
