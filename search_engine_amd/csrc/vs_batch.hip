@@ -35,9 +35,9 @@
 // Without a bound, or when a tile overflows the queue, the tile's scores go
 // through LDS in four chunks of 64 rows and every owner walks its column.
 //
-// The launcher runs two passes: the first 256 tiles without a bound, a merge
-// that turns their lists into the per-query k-th best of that sample, and the
-// rest of the store with it as the bound.
+// The launcher runs two passes: 256 tiles spread evenly over the store without a
+// bound, a merge that turns their lists into the per-query k-th best of that
+// sample, and the rest of the store with it as the bound.
 #include "vs_kernels.h"
 
 #include "../../include/vs_abi.h"
@@ -91,7 +91,10 @@ struct BatchArgs {
     uint32_t docid_base;
     uint32_t k;
     uint32_t n_q;
-    uint32_t tile0, tile_end;  // tiles [tile0, tile_end) of 256 rows
+    // Tiles of 256 rows. The sample = tiles 0, stride, 2*stride, ... (sample_count of them).
+    // pass 1: workgroup b scans sample tile b (gridDim.x == sample_count); pass 2: workgroup b
+    // scans the non-sample tiles among b, b + gridDim.x, ...
+    uint32_t n_tiles, sample_stride, sample_count, pass;
     uint32_t lists;            // gridDim.x, + 1 when bound_keys is carried along as a list of its own
 };
 
@@ -140,12 +143,13 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
     float* sqn = reinterpret_cast<float*>(smem + OFF_QNORM);
     uint64_t* sbound = reinterpret_cast<uint64_t*>(smem + OFF_BOUND);
     uint64_t my_tau = (owner && a.bound_keys) ? a.bound_keys[(uint64_t)tid * k + (k - 1)] : KEY_NONE;
+    uint32_t tile_docid0 = 0;  // first docid of the tile being judged (owners only need it for a zero query)
     int my_cnt = 0;  // entries in my list
     // pq >= c2 * pn is necessary for a row to beat tau: d < dthr <=> pq > (1 - 2 dthr) qn pn.
     auto threshold = [&](float qn) -> float {
         if (my_tau == KEY_NONE) return -3.0e38f;
-        // a zero query is at distance 0 from everything: once tau is set no later (higher) docid beats it
-        if (qn == 0.0f) return 3.0e38f;
+        // a zero query is at distance 0 from everything: once tau is set only a lower docid beats it
+        if (qn == 0.0f) return tile_docid0 > (uint32_t)my_tau ? 3.0e38f : -3.0e38f;
         const float c = (1.0f - 2.0f * f32_from_orderable((uint32_t)(my_tau >> 32))) * qn - qn * 1e-6f;
         return c == c ? c : -3.0e38f;
     };
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
     const __amdgpu_buffer_rsrc_t qres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<u32x4*>(a.qrows), 0, (int)((uint32_t)BN * KS * 128u), 0x00020000);
     auto doc_rsrc = [&](uint32_t tile) {
-        const bool live = tile < a.tile_end;
+        const bool live = tile < a.n_tiles;
         return __builtin_amdgcn_make_buffer_rsrc(
             const_cast<u32x4*>(a.rows + (live ? (uint64_t)tile * BM * a.row_vecs : 0)), 0,
             live ? (int)((uint32_t)BM * row_bytes) : 0, 0x00020000);
@@ -274,10 +278,23 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
     const uint32_t frag_a = swz(wm * 64 + r32, half), frag_b = IMG_B + swz(wn * 128 + r32, half);
     uint32_t image = 0;  // DMA: the image the step about to be computed lands in
 
-    load_step(a.tile0 + blockIdx.x, 0, image);
+    // this workgroup's tiles, ascending
+    auto skip_sample = [&](uint32_t t) {
+        while (t < a.n_tiles && t % a.sample_stride == 0 && t / a.sample_stride < a.sample_count) t += gridDim.x;
+        return t;
+    };
+    auto tile_after = [&](uint32_t t) { return a.pass == 1 ? a.n_tiles : skip_sample(t + gridDim.x); };
+    uint32_t tile = a.pass == 1 ? blockIdx.x * a.sample_stride : skip_sample(blockIdx.x);
+    load_step(tile, 0, image);
 
-    for (uint32_t tile = a.tile0 + blockIdx.x; tile < a.tile_end; tile += gridDim.x) {
+    for (; tile < a.n_tiles;) {
+        const uint32_t next_tile = tile_after(tile);
         const uint64_t row0 = (uint64_t)tile * BM;
+        if (owner && sqn[tid] == 0.0f) {  // a zero query's threshold depends on where the tile lies
+            tile_docid0 = a.docid_base + (uint32_t)row0;
+            const float c = threshold(0.0f);
+            if (c != my_c2) c2[tid] = my_c2 = c;  // (read again only after this tile's barriers)
+        }
         // this wave's 64 rows are exactly one word of the candidate mask
         uint64_t w[4];
         uint64_t any = 0;
@@ -291,7 +308,8 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
         }
         if (any == 0) {  // no candidate in this tile: restart the stream at the next one
             if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the same image is about to be refilled
-            load_step(tile + gridDim.x, 0, image);
+            load_step(next_tile, 0, image);
+            tile = next_tile;
             continue;
         }
         uint32_t* qcount = qcounts + par;
@@ -326,7 +344,7 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
                 if (ks + 1 < KS)
                     load_step(tile, ks + 1, image);
                 else
-                    load_step(tile + gridDim.x, 0, image);
+                    load_step(next_tile, 0, image);
             } else {
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
@@ -337,7 +355,7 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
                 if (ks + 1 < KS)
                     load_step(tile, ks + 1, 0);
                 else
-                    load_step(tile + gridDim.x, 0, 0);
+                    load_step(next_tile, 0, 0);
             }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
@@ -430,6 +448,7 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
                             consider(row0, (uint32_t)e[j] & 0xFFu, __uint_as_float((uint32_t)(e[j] >> 32)));
                 }
             }
+            tile = next_tile;
             continue;  // the next tile's first barrier closes this epilogue
         }
 
@@ -479,6 +498,7 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
             }
         }
         if constexpr (FIRST) break;  // one tile per workgroup
+        tile = next_tile;
     }
 
     if (tid < a.n_q) {
@@ -522,7 +542,7 @@ __global__ __launch_bounds__(256) void prep_queries_bf16_kernel(const float* que
 namespace {
 
 struct BatchPlan {
-    uint32_t ksteps, n_tiles, sample_tiles, blocks1, blocks2;
+    uint32_t ksteps, n_tiles, sample_tiles, sample_stride, blocks1, blocks2;
     size_t off_qnorm, off_sample, off_partial1, off_partial2, total;
 };
 
@@ -531,6 +551,12 @@ BatchPlan plan_batch(const SlabView& s, uint32_t k) {
     p.ksteps = (s.row_vecs + 7) / 8;
     p.n_tiles = (uint32_t)((s.n_slots + BM - 1) / BM);
     p.sample_tiles = p.n_tiles < (uint32_t)SAMPLE_TILES ? p.n_tiles : (uint32_t)SAMPLE_TILES;
+    // Sample tiles are spread over the whole store (a filter may select one docid range only).
+    // An odd stride: the tiles of a workgroup of the second pass are 256 apart, so each loses
+    // at most one tile to the sample and the passes stay balanced.
+    p.sample_stride = p.n_tiles / (uint32_t)SAMPLE_TILES;
+    if (p.sample_stride < 1) p.sample_stride = 1;
+    if (!(p.sample_stride & 1)) p.sample_stride -= 1;
     p.blocks1 = p.sample_tiles < 1 ? 1 : p.sample_tiles;
     const uint32_t rest = p.n_tiles - p.sample_tiles;
     p.blocks2 = rest > 256 ? 256 : rest;
@@ -595,8 +621,10 @@ hipError_t launch_scan_batch_bf16(const SlabView& s, const float* d_queries, uin
     const bool two = p.blocks2 > 0;
     a.bound_keys = nullptr;
     a.partial = partial1;
-    a.tile0 = 0;
-    a.tile_end = p.sample_tiles;
+    a.n_tiles = p.n_tiles;
+    a.sample_stride = p.sample_stride;
+    a.sample_count = p.sample_tiles;
+    a.pass = 1;
     a.lists = p.blocks1;
     hipLaunchKernelGGL(first, dim3(p.blocks1), dim3(BTHREADS), lds, stream, a);
     e = hipGetLastError();
@@ -610,8 +638,7 @@ hipError_t launch_scan_batch_bf16(const SlabView& s, const float* d_queries, uin
     // pass 2: everything else, bounded by the sample's k-th best
     a.bound_keys = sample;
     a.partial = partial2;
-    a.tile0 = p.sample_tiles;
-    a.tile_end = p.n_tiles;
+    a.pass = 2;
     a.lists = p.blocks2 + 1;
     hipLaunchKernelGGL(kernel, dim3(p.blocks2), dim3(BTHREADS), lds, stream, a);
     e = hipGetLastError();

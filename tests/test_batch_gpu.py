@@ -88,12 +88,13 @@ def test_batch_parity_filters_and_holes(gpu_ctx, pass_percent):
         store.destroy()
 
 
-@pytest.mark.parametrize("pass_percent,k", [(None, 10), (3, 10), (50, 32)])
+@pytest.mark.parametrize("pass_percent,k", [(None, 10), (3, 10), (50, 32), ("top third", 10)])
 def test_batch_parity_beyond_the_sample_pass(gpu_ctx, pass_percent, k):
-    """More than 256 tiles of 256 rows: the first 65536 slots are scanned without a bound, the rest
-    against the k-th best of that sample (register test, survivor queue). The best rows are planted
-    at both ends, in the middle and in the padding-sized tail so that every path has to deliver."""
-    n, dim = 65536 * 2 + 64 * 3, 64
+    """More than 3 x 256 tiles of 256 rows: 256 tiles spread over the store (every third) are
+    scanned without a bound, the rest against the k-th best of that sample (register test,
+    survivor queue). The best rows are planted all over the store so that every path has to
+    deliver; one filter selects the top third of the docids only."""
+    n, dim = 256 * 256 * 3 + 64 * 3, 64
     vectors = synthetic_vectors(n, dim, 0x7A11)
     queries = synthetic_vectors(37, dim, 0x7A12)
     rng = np.random.default_rng(5)
@@ -104,8 +105,13 @@ def test_batch_parity_beyond_the_sample_pass(gpu_ctx, pass_percent, k):
     vectors[70000] = 0.0          # zero-norm row in the bounded pass
     vectors[100000, 0] = np.inf   # non-finite rows: their tile takes the chunked walk; NaN distances sort last
     vectors[100300, 3] = np.nan
-    queries[5] = 0.0              # zero query: first k candidate docids
-    mask = None if pass_percent is None else facet_mask(n, pass_percent)
+    queries[5] = 0.0              # zero query: the first k candidate docids, some of them in second-pass tiles
+    if pass_percent is None:
+        mask = None
+    elif pass_percent == "top third":
+        mask = oracle.bool_to_mask(np.arange(n) >= 2 * n // 3)
+    else:
+        mask = facet_mask(n, pass_percent)
     store = make_bf16_store(gpu_ctx, vectors)
     try:
         check_batch(store, vectors, queries, k, mask)
