@@ -127,6 +127,44 @@ __device__ __forceinline__ uint64_t wave_shift_up_u64(uint64_t v, uint64_t fill)
     return ((uint64_t)hi << 32) | lo;
 }
 
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, mask, 64);
+    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), mask, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t min_u64(uint64_t a, uint64_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint64_t max_u64(uint64_t a, uint64_t b) { return a < b ? b : a; }
+
+// 128 keys per wave, element i in `lo` of lane i (i < 64) or `hi` of lane i - 64.
+// A bitonic sequence becomes ascending: the last phase of a bitonic sort.
+__device__ __forceinline__ void bitonic_merge128(uint64_t& lo, uint64_t& hi, int lane) {
+    const uint64_t a = min_u64(lo, hi), b = max_u64(lo, hi);  // distance 64: inside the lane
+    lo = a;
+    hi = b;
+#pragma unroll
+    for (int j = 32; j >= 1; j >>= 1) {
+        const uint64_t plo = shfl_xor_u64(lo, j), phi = shfl_xor_u64(hi, j);
+        const bool upper = lane & j;
+        lo = upper ? max_u64(lo, plo) : min_u64(lo, plo);
+        hi = upper ? max_u64(hi, phi) : min_u64(hi, phi);
+    }
+}
+// Any 128 keys become ascending (27 compare-exchange phases).
+__device__ __forceinline__ void bitonic_sort128(uint64_t& lo, uint64_t& hi, int lane) {
+#pragma unroll
+    for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+        for (int j = size >> 1; j >= 1; j >>= 1) {
+            const uint64_t plo = shfl_xor_u64(lo, j), phi = shfl_xor_u64(hi, j);
+            const bool upper = lane & j;
+            const bool desc_lo = lane & size, desc_hi = (64 + lane) & size;  // blocks alternate direction
+            lo = (upper != desc_lo) ? max_u64(lo, plo) : min_u64(lo, plo);
+            hi = (upper != desc_hi) ? max_u64(hi, phi) : min_u64(hi, phi);
+        }
+    }
+    bitonic_merge128(lo, hi, lane);  // lo ascending, hi descending: bitonic
+}
+
 // The k smallest keys one wave has seen, ascending. For k <= 128 the list lives in
 // two register pairs (lane i holds the i-th and the (64+i)-th smallest) and an
 // insert is two compares, two ballots and a cross-lane shift; larger k use the
@@ -168,6 +206,16 @@ struct WaveTopK {
             tau = list_insert(lds, k, key, lane);
         }
     }
+    // Register lists only, list still empty: takes 128 arbitrary keys (two per lane, KEY_NONE =
+    // none) at the cost of one sort instead of up to 128 inserts.
+    __device__ __forceinline__ void fill128(uint64_t a, uint64_t b) {
+        lo = a;
+        hi = b;
+        bitonic_sort128(lo, hi, lane);
+        if (lane >= k) lo = KEY_NONE;
+        if (lane + 64 >= k) hi = KEY_NONE;
+        tau = k <= 64 ? readlane_u64(lo, k - 1) : readlane_u64(hi, k - 65);
+    }
     // after this the list can be read from `lds` (by this wave, or by others
     // after a workgroup barrier)
     __device__ __forceinline__ void spill() {
@@ -179,6 +227,19 @@ struct WaveTopK {
     }
     // inserts every entry below tau of another wave's spilled list
     __device__ __forceinline__ void absorb(uint64_t* other) {
+        if (in_regs) {
+            // Two ascending lists A (mine) and B: C[i] = min(A[i], B[127 - i]) holds the 128 smallest
+            // of both and is bitonic; one merge phase sorts it. A handful of instructions against
+            // one insert per entry.
+            const int ia = 127 - lane, ib = 63 - lane;
+            lo = min_u64(lo, ia < k ? other[ia] : KEY_NONE);
+            hi = min_u64(hi, ib < k ? other[ib] : KEY_NONE);
+            bitonic_merge128(lo, hi, lane);
+            if (lane >= k) lo = KEY_NONE;
+            if (lane + 64 >= k) hi = KEY_NONE;
+            tau = k <= 64 ? readlane_u64(lo, k - 1) : readlane_u64(hi, k - 65);
+            return;
+        }
         for (int j = 0; j < k; ++j) {
             const uint64_t key = uniform_u64(other[j]);
             if (key >= tau) break;

@@ -386,8 +386,15 @@ __global__ __launch_bounds__(256) void merge_kernel(const uint64_t* keys, uint32
             for (int b = 0; b < 4; ++b) key[b] = nxt[b];
             if (r + 1 < n_ranks) load_rank(r + 1, nxt);
             bool any = false;
+            int b0 = 0;
+            if (r == 0 && base == 0 && top.in_regs) {  // the list is empty: 128 keys at the price of one sort
+                top.fill128(key[0], key[1]);
+                any = true;
+                b0 = 2;
+            }
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
+                if (b < b0) continue;
                 uint64_t m = __ballot(key[b] < top.tau);
                 while (m) {
                     const int src = __builtin_ctzll(m);
