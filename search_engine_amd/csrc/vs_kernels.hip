@@ -110,12 +110,17 @@ __device__ __forceinline__ float angular_distance(float pq, float pn, float qn) 
 // following batch is requested before this one is scored); words with a set bit
 // are then taken one at a time, their passing slots appended to the wave's queue
 // in LDS, and score(head, n) is called for GROUP queued slots at a time (the
-// last call may get fewer: n < GROUP).
-template <int GROUP, typename ScoreFn>
+// last call may get fewer: n < GROUP). A kernel may also offer dense(slot0, word):
+// it is then given the (nearly) full words whole, bypassing the queue.
+struct NoDenseFn {
+    __device__ __forceinline__ bool wants(uint64_t) const { return false; }
+    __device__ __forceinline__ void operator()(uint32_t, uint64_t) const {}
+};
+template <int GROUP, typename ScoreFn, typename DenseFn = NoDenseFn>
 __device__ __forceinline__ void scan_masked_slots(const uint64_t* __restrict__ present,
                                                   const uint64_t* __restrict__ cand,
                                                   uint64_t n_slots, uint32_t w, uint32_t W, int lane,
-                                                  uint32_t* queue, ScoreFn&& score) {
+                                                  uint32_t* queue, ScoreFn&& score, DenseFn&& dense = DenseFn()) {
     static_assert(GROUP <= QCAP - 64, "queue too small");
     const uint64_t n_words = n_slots >> 6;
     const uint64_t my_words = w < n_words ? (n_words - w + W - 1) / W : 0;
@@ -140,6 +145,10 @@ __device__ __forceinline__ void scan_masked_slots(const uint64_t* __restrict__ p
             nz &= nz - 1;
             const uint64_t word = readlane_u64(wd, b);
             const uint32_t slot0 = (uint32_t)(((uint64_t)w + (t0 + (uint64_t)b) * W) << 6);
+            if (dense.wants(word)) {
+                dense(slot0, word);
+                continue;
+            }
             if ((word >> lane) & 1) queue[qcount + lanes_below(word)] = slot0 + (uint32_t)lane;
             qcount += (uint32_t)__popcll(word);
             wave_lds_fence();
@@ -271,6 +280,69 @@ struct HammingArgs {
     uint32_t k;
 };
 
+// Dense stretches of 192-byte rows. A row is one and a half 128-byte lines, so the quad
+// schedule above asks for half lines; here EIGHT lanes share a PAIR of rows (384 bytes = three
+// whole lines): lane j of the eight loads vectors j, j + 8, j + 16 of the pair, each
+// instruction reads one whole line per pair, and a wave covers the 64 slots of a mask word
+// in four passes of eight pairs. Vector v of the pair belongs to row v / 12 and lines up with
+// query vector v % 12; which is which is fixed per lane. Three DPP adds per row finish it.
+template <bool NT>
+struct HammingPairs {
+    const u32x4* rows;
+    uint32_t docid_base;
+    int lane;
+    WaveTopK* top;
+    u32x4 q[3];  // query vectors j, (j + 8) % 12, j + 4 for this lane's j = lane & 7
+
+    __device__ __forceinline__ void load_query(const u32x4* query) {
+        const uint32_t j = (uint32_t)lane & 7;
+        q[0] = query[j];
+        q[1] = query[(j + 8) % 12];
+        q[2] = query[j + 4];
+    }
+    // enough candidates that reading all 64 rows beats picking them one by one
+    __device__ __forceinline__ bool wants(uint64_t word) const { return __popcll(word) >= 56; }
+    __device__ __forceinline__ void operator()(uint32_t slot0, uint64_t word) {
+        const uint32_t j = (uint32_t)lane & 7, g = (uint32_t)lane >> 3;
+        u32x4 x[4][3];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const u32x4* rp = rows + ((uint64_t)slot0 + 2u * ((uint32_t)p * 8 + g)) * 12 + j;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) x[p][i] = load_vec<NT>(rp + 8 * i);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            uint32_t c[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                c[i] = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) c[i] += (uint32_t)__popc(x[p][i][e] ^ q[i][e]);
+            }
+            // vector j: first row; vector j + 16: second row; vector j + 8: first row iff j < 4
+            uint32_t ca = c[0] + (j < 4 ? c[1] : 0u), cb = c[2] + (j < 4 ? 0u : c[1]);
+            ca += dpp_u32<0xB1, 0xF>(ca);   // quad_perm [1,0,3,2]
+            cb += dpp_u32<0xB1, 0xF>(cb);
+            ca += dpp_u32<0x4E, 0xF>(ca);   // quad_perm [2,3,0,1]
+            cb += dpp_u32<0x4E, 0xF>(cb);
+            ca += dpp_u32<0x141, 0xF>(ca);  // row_half_mirror: the other quad of the eight
+            cb += dpp_u32<0x141, 0xF>(cb);
+            // lanes 0 and 1 of the eight speak for the first and the second row
+            const uint32_t r = 2u * ((uint32_t)p * 8 + g) + (j & 1);
+            const uint64_t key = make_key(j == 0 ? ca : cb, docid_base + slot0 + r);
+            const bool live = j < 2 && ((word >> r) & 1);
+            uint64_t m = __ballot(live && key < top->tau);
+            while (m) {
+                const int src = __builtin_ctzll(m);
+                top->insert(readlane_u64(key, src));
+                m &= m - 1;
+                m &= __ballot(live && key < top->tau);
+            }
+        }
+    }
+};
+
 template <int NI, int U, bool NT>
 __global__ __launch_bounds__(WAVES * 64) void scan_hamming_kernel(HammingArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -335,6 +407,15 @@ __global__ __launch_bounds__(WAVES * 64) void scan_hamming_kernel(HammingArgs a)
         }
     };
 
+    if constexpr (NI == 3) {
+        if (a.row_vecs == 12) {  // 1536-bit rows: whole words of candidates go through the pair path
+            HammingPairs<NT> pairs{a.rows, a.docid_base, lane, &top};
+            pairs.load_query(a.query);
+            scan_masked_slots<16 * U>(a.present, a.cand, a.n_slots, w, W, lane, queue, score_rows, pairs);
+            finish_block(top, smem, k, wib, lane, a.partial);
+            return;
+        }
+    }
     scan_masked_slots<16 * U>(a.present, a.cand, a.n_slots, w, W, lane, queue, score_rows);
     finish_block(top, smem, k, wib, lane, a.partial);
 }
