@@ -468,7 +468,9 @@ __global__ __launch_bounds__(256) void merge_kernel(const uint64_t* keys, uint32
             if (r + 1 < n_ranks) load_rank(r + 1, nxt);
             bool any = false;
             int b0 = 0;
-            if (r == 0 && base == 0 && top.in_regs) {  // the list is empty: 128 keys at the price of one sort
+            // the list is empty: 128 keys at the price of one sort (a handful of keys are cheaper inserted)
+            if (r == 0 && base == 0 && top.in_regs &&
+                __popcll(__ballot(key[0] != KEY_NONE)) + __popcll(__ballot(key[1] != KEY_NONE)) >= 24) {
                 top.fill128(key[0], key[1]);
                 any = true;
                 b0 = 2;

@@ -299,6 +299,61 @@ int32_t run_batch_and_fetch(vs_store* s, Workspace* ws, const float* h_queries, 
     return VS_OK;
 }
 
+// Several queries under one candidate mask, one scan each (f32 and binary stores, or k beyond
+// the matrix-core path): the scans of a chunk are queued back to back on the workspace's
+// stream, with ONE upload of the queries, ONE download of the results and ONE wait per chunk.
+int32_t run_many_and_fetch(vs_store* s, Workspace* ws, const float* h_queries, uint32_t n_q, uint32_t k,
+                           const uint64_t* d_cand, uint32_t* out_ids, float* out_dist, uint32_t* out_n) {
+    const vs::SlabView v = s->view();
+    const vs::ScanTuning& t = s->ctx->tuning;
+    if (int32_t rc = grow(&ws->d_partial, &ws->partial_bytes, (size_t)vs::scan_partial_bytes(v, k, t)))
+        return rc;
+    const size_t chunk_q = 64;
+    const bool bin = s->dtype == VS_BIN1;
+    const size_t q_bytes = bin ? (size_t)s->row_vecs * 16 : (size_t)s->dim * 4;  // per query, on the device
+    const size_t q_stride = (q_bytes + 255) / 256 * 256;
+    const size_t res_bytes = chunk_q * k * 8 + chunk_q * 4;  // ids, distances, counts
+    if (int32_t rc = grow(&ws->d_batch, &ws->batch_bytes, chunk_q * q_stride + res_bytes)) return rc;
+    std::vector<unsigned char> hq(chunk_q * q_stride), hr(res_bytes);
+    for (uint32_t at = 0; at < n_q; at += (uint32_t)chunk_q) {
+        const uint32_t m = n_q - at < chunk_q ? n_q - at : (uint32_t)chunk_q;
+        for (uint32_t i = 0; i < m; ++i) {
+            const float* q = h_queries + (size_t)(at + i) * s->dim;
+            unsigned char* dst = hq.data() + i * q_stride;
+            if (bin) {  // quantised like the rows: bit j = (q[j] > 0), zero padded to whole vectors
+                uint64_t* w = reinterpret_cast<uint64_t*>(dst);
+                memset(w, 0, q_bytes);
+                for (uint32_t j = 0; j < s->dim; ++j)
+                    if (q[j] > 0.0f) w[j >> 6] |= 1ull << (j & 63);
+            } else {
+                memcpy(dst, q, q_bytes);
+            }
+        }
+        unsigned char* d_res = ws->d_batch + chunk_q * q_stride;
+        uint32_t* d_ids = reinterpret_cast<uint32_t*>(d_res);
+        float* d_dist = reinterpret_cast<float*>(d_res + chunk_q * k * 4);
+        uint32_t* d_n = reinterpret_cast<uint32_t*>(d_res + chunk_q * k * 8);
+        HIP_TRY(hipMemcpyAsync(ws->d_batch, hq.data(), (size_t)m * q_stride, hipMemcpyHostToDevice, ws->stream));
+        for (uint32_t i = 0; i < m; ++i)
+            if (int32_t rc = launch_scan(s, ws->d_batch + i * q_stride, d_cand, k, ws->d_partial, nullptr,
+                                         d_ids + (size_t)i * k, d_dist + (size_t)i * k, d_n + i, ws->stream))
+                return rc;
+        HIP_TRY(hipMemcpyAsync(hr.data(), d_res, res_bytes, hipMemcpyDeviceToHost, ws->stream));
+        HIP_TRY(hipStreamSynchronize(ws->stream));
+        const uint32_t* h_ids = reinterpret_cast<const uint32_t*>(hr.data());
+        const float* h_dist = reinterpret_cast<const float*>(hr.data() + chunk_q * k * 4);
+        const uint32_t* h_n = reinterpret_cast<const uint32_t*>(hr.data() + chunk_q * k * 8);
+        for (uint32_t i = 0; i < m; ++i) {
+            const uint32_t n = h_n[i];
+            if (n > k) return fail(VS_E_DEVICE, "device returned %u results for k = %u", n, k);
+            memcpy(out_ids + (size_t)(at + i) * k, h_ids + (size_t)i * k, (size_t)n * 4);
+            memcpy(out_dist + (size_t)(at + i) * k, h_dist + (size_t)i * k, (size_t)n * 4);
+            out_n[at + i] = n;
+        }
+    }
+    return VS_OK;
+}
+
 // Copies the caller's docid-indexed mask into ws->d_mask, aligned to the store.
 int32_t stage_dense_mask(vs_store* s, Workspace* ws, const uint64_t* mask_words,
                          uint64_t n_mask_words) {
@@ -802,10 +857,8 @@ extern "C" int32_t vs_search_batch(vs_store* s, const float* queries, uint32_t n
     }
     if (rc == VS_OK && s->dtype == VS_BF16 && k <= VS_BATCH_MAX_K && n_q > 1) {
         rc = run_batch_and_fetch(s, ws.get(), queries, n_q, k, d_cand, out_ids, out_dist, out_n);
-    } else {
-        for (uint32_t i = 0; i < n_q && rc == VS_OK; ++i)
-            rc = run_and_fetch(s, ws.get(), queries + (size_t)i * dim, k, d_cand, out_ids + (size_t)i * k,
-                               out_dist + (size_t)i * k, out_n + i);
+    } else if (rc == VS_OK) {
+        rc = run_many_and_fetch(s, ws.get(), queries, n_q, k, d_cand, out_ids, out_dist, out_n);
     }
     ws_release(s->ctx, std::move(ws));
     return rc;

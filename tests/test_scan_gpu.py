@@ -327,6 +327,34 @@ def test_search_batch_and_roaring(gpu_ctx):
         store.destroy()
 
 
+@pytest.mark.parametrize("kind", ["f32", "bin1", "bf16 k=40"])
+def test_search_batch_without_the_matrix_core_path(gpu_ctx, kind):
+    """vs_search_batch where it is a queue of single-query scans (f32 and binary stores, bf16 with
+    k beyond 32): the same lists as vs_search, for more queries than one chunk holds."""
+    from search_engine_amd import abi
+    n, dim = 9000, 192
+    vectors = synthetic_vectors(n, dim, 201)
+    queries = synthetic_vectors(150, dim, 202)
+    mask = facet_mask(n, 50)
+    if kind == "bin1":
+        _next_index[0] += 1
+        store = gpu_ctx.create_store(_next_index[0], dim, n, dtype=abi.VS_BIN1, metric=abi.VS_HAMMING)
+        store.upload(np.arange(n, dtype=np.uint32), vectors)
+        store.seal()
+    else:
+        store = make_store(gpu_ctx, vectors, dtype=abi.VS_F32 if kind == "f32" else abi.VS_BF16)
+    k = 40 if kind == "bf16 k=40" else 10
+    try:
+        batch = store.search_batch(queries, k, mask)
+        assert len(batch) == len(queries)
+        for q, (ids, dist) in zip(queries, batch):
+            s_ids, s_dist = store.search(q, k, mask)
+            assert ids.tolist() == s_ids.tolist() and dist.tolist() == s_dist.tolist()
+        assert store.search_batch(queries[:3], 0, mask)[0][0].size == 0
+    finally:
+        store.destroy()
+
+
 def test_masks_kept_on_the_device(gpu_ctx):
     """vs_mask_*: a filter uploaded once (dense words or serialised roaring) gives the results of
     vs_search with the same filter, for every query, before and after the store changes."""
