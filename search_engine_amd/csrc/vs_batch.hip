@@ -277,6 +277,7 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
 
     const uint32_t frag_a = swz(wm * 64 + r32, half), frag_b = IMG_B + swz(wn * 128 + r32, half);
     uint32_t image = 0;  // DMA: the image the step about to be computed lands in
+    bool ahead = false;  // DMA: step 1 of the coming tile is already in flight (into the other image)
 
     // this workgroup's tiles, ascending
     auto skip_sample = [&](uint32_t t) {
@@ -286,6 +287,17 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
     auto tile_after = [&](uint32_t t) { return a.pass == 1 ? a.n_tiles : skip_sample(t + gridDim.x); };
     uint32_t tile = a.pass == 1 ? blockIdx.x * a.sample_stride : skip_sample(blockIdx.x);
     load_step(tile, 0, image);
+    // lane j < 4: candidate word j of tile t (present & filter), 0 past the end
+    auto load_words = [&](uint32_t t) -> uint64_t {
+        const uint64_t wi = 4 * (uint64_t)t + (lane & 3);
+        uint64_t x = 0;
+        if (t < a.n_tiles && wi < n_words) {
+            x = a.present[wi];
+            if (a.cand) x &= a.cand[wi];
+        }
+        return x;
+    };
+    uint64_t w_ahead = load_words(tile);
 
     for (; tile < a.n_tiles;) {
         const uint32_t next_tile = tile_after(tile);
@@ -295,19 +307,20 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
             const float c = threshold(0.0f);
             if (c != my_c2) c2[tid] = my_c2 = c;  // (read again only after this tile's barriers)
         }
-        // this wave's 64 rows are exactly one word of the candidate mask
+        // The tile's four candidate words (a wave's 64 rows are exactly one of them) were
+        // requested a tile ago by lanes 0..3; the next tile's are requested now and arrive
+        // under this tile's K loop.
         uint64_t w[4];
         uint64_t any = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint64_t wi = 4 * (uint64_t)tile + j;
-            uint64_t x = wi < n_words ? a.present[wi] : 0;
-            if (a.cand && wi < n_words) x &= a.cand[wi];
-            w[j] = uniform_u64(x);
+            w[j] = readlane_u64(w_ahead, j);
             any |= w[j];
         }
+        w_ahead = load_words(next_tile);
         if (any == 0) {  // no candidate in this tile: restart the stream at the next one
             if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the same image is about to be refilled
+            ahead = false;
             load_step(next_tile, 0, image);
             tile = next_tile;
             continue;
@@ -323,7 +336,12 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
                 for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
 
         for (uint32_t ks = 0; ks < KS; ++ks) {
-            if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): my pieces of this step are in LDS
+            if constexpr (DMA) {  // my pieces of this step are in LDS (step 1's eight may still be on their way)
+                if (ks == 0 && ahead)
+                    __builtin_amdgcn_s_waitcnt(0x0F78);  // vmcnt(8)
+                else
+                    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+            }
             // everyone's pieces are; the previous step's readers, or the previous tile's epilogue, are done
             __syncthreads();
             if (ks == 0) {
@@ -341,7 +359,9 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
             if constexpr (DMA) {
                 img += image * IMG_BYTES;
                 image ^= 1u;
-                if (ks + 1 < KS)
+                if (ks == 0 && ahead)
+                    ahead = false;  // this tile's step 1 was requested during the previous tile's drain
+                else if (ks + 1 < KS)
                     load_step(tile, ks + 1, image);
                 else
                     load_step(next_tile, 0, image);
@@ -436,6 +456,14 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
         __syncthreads();
         const uint32_t n_queued = reg_test ? *qcount : (uint32_t)QCAP + 1u;
         if (n_queued <= (uint32_t)QCAP) {
+            if constexpr (DMA && !FIRST) {
+                // Nobody reads an image any more (the walk below would): the one the last step used
+                // can already take step 1 of the coming tile while the survivors are drained.
+                if (KS > 1) {
+                    load_step(next_tile, 1, image ^ 1u);
+                    ahead = true;
+                }
+            }
             if (owner) {
 #pragma unroll 1
                 for (uint32_t i = 0; i < n_queued; i += 4) {  // (entries past n_queued are stale, never out of bounds)
