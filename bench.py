@@ -70,6 +70,9 @@ def main():
                     help="further pass rates reported in `sweep` (N = 1 only)")
     ap.add_argument("--queries-per-step", type=int, default=16)
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--batch-queries", type=int, default=0,
+                    help="not the headline: N > 0 times the batched matrix-core scan instead "
+                         "(bf16 store, N <= 256 queries per step share one pass over the shard)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=500_000)
     args = ap.parse_args()
@@ -118,6 +121,13 @@ def main():
     n_slots = -(-max(n_local, 64) // 64) * 64
     row_bytes = store.row_bytes
     from search_engine_amd import sharded
+    if args.batch_queries:
+        batched_bench(args, ctx, store, dev, stream, queries, first, n_slots, n_local, rank, world)
+        store.destroy()
+        ctx.close()
+        if world > 1:
+            dist.destroy_process_group()
+        return
     cur = {"step": 0, "mask": None, "events": None}
     searcher = sharded.gpu_sharded_search(
         ctx, store, k, qps_batch, dev,
@@ -261,6 +271,58 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def batched_bench(args, ctx, store, dev, stream, queries, first, n_slots, n_local, rank, world):
+    """BASELINE config 3: `--batch-queries` queries per step against a bf16 store sharded over the
+    ranks; one vs_search_batch_device per rank, one all-gather of the keys, one merge launch."""
+    import torch.distributed as dist
+    from search_engine_amd import sharded
+    if args.dtype != "bf16" or not 0 < args.batch_queries <= 256:
+        raise SystemExit("--batch-queries needs --dtype bf16 and at most 256 queries")
+    b, k, dim = args.batch_queries, args.k, args.dim
+    mask = device_mask(first, n_slots, args.pass_percent, dev)
+    cur = {"step": 0}
+    searcher = sharded.gpu_sharded_batch_search(
+        ctx, store, k, b, dev, queries_ptr=lambda: queries[(cur["step"] * b) % (1024 - b + 1):].data_ptr(),
+        mask_ptr=lambda: mask.data_ptr(), stream=lambda: stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        cur["step"] = i
+        searcher.run()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        cur["step"] = args.warmup + i
+        searcher.run()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        flop = 2.0 * args.docs * dim * 256  # a launch always computes 256 query columns
+        ms = 1e3 * dt / args.steps
+        print(json.dumps({
+            "metric": "batched top-10 vector QPS (matrix-core scan), 256 queries per step",
+            "value": round(args.steps * b / dt, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.docs} docs x {dim}-dim bf16 cosine, {b} queries per step, top-{k}, "
+                                   f"facet pass rate {args.pass_percent}%", "docs": args.docs, "dim": dim, "k": k,
+                       "parallelism": f"docid-range shards x{world}, one all-gather of top-k keys per step"},
+            "roofline": {"bound": "hbm", "achieved": round(args.docs * dim * 2 / (ms * 1e-3) / 1e9, 1),
+                         "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
+                         "frac": round(args.docs * dim * 2 / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world), 4),
+                         "traffic": None, "mfma_tflops": round(flop / (ms * 1e-3) / 1e12, 1),
+                         "mfma_frac_of_2500_per_gpu": round(flop / (ms * 1e-3) / 1e12 / (2500.0 * world), 4)},
+        }), flush=True)
 
 
 def cpu_baseline(sample, queries, args, dim, k):

@@ -60,8 +60,11 @@ class ShardedSearch:
     exercise the sharding and the collective under gloo.
     """
 
-    def __init__(self, local_search, merge, k, batch, device, group=None):
+    def __init__(self, local_search, merge, k, batch, device, group=None, local_search_all=None):
         self.local_search = local_search
+        # optional: searches queries 0..n-1 in one go, keys[j*k:(j+1)*k] = query j (one pass over
+        # the shard for all of them instead of one per query)
+        self.local_search_all = local_search_all
         self.merge = merge
         self.k = k
         self.batch = batch
@@ -74,8 +77,11 @@ class ShardedSearch:
     def run(self, n_queries=None):
         """Searches queries 0..n_queries-1 of the current batch (default: a full batch)."""
         n = self.batch if n_queries is None else n_queries
-        for j in range(n):
-            self.local_search(j, self.keys[j * self.k:(j + 1) * self.k])
+        if self.local_search_all is not None:
+            self.local_search_all(n, self.keys)
+        else:
+            for j in range(n):
+                self.local_search(j, self.keys[j * self.k:(j + 1) * self.k])
         if self.world > 1:
             dist.all_gather_into_tensor(self.gathered, self.keys, group=self.group)
         return self.merge(self.gathered, self.world, n, self.k)
@@ -102,5 +108,30 @@ def gpu_sharded_search(ctx, store, k, batch, device, query_ptr, mask_ptr, stream
         return out_ids, out_dist, out_n
 
     s = ShardedSearch(local_search, merge, k, batch, device, group)
+    s.workspace = ws  # keep alive
+    return s
+
+
+def gpu_sharded_batch_search(ctx, store, k, batch, device, queries_ptr, mask_ptr, stream, group=None):
+    """ShardedSearch whose local step is ONE vs_search_batch_device call (bf16 store, k <= 32,
+    batch <= 256: the scan on the matrix cores). queries_ptr() -> device address of the batch's
+    f32 queries [batch][dim]."""
+    from . import abi
+    ws = torch.empty(store.batch_workspace_bytes(k), dtype=torch.uint8, device=device)
+    out_ids = torch.empty(batch * k, dtype=torch.int32, device=device)
+    out_dist = torch.empty(batch * k, dtype=torch.float32, device=device)
+    out_n = torch.empty(batch, dtype=torch.int32, device=device)
+    dim = store.dim
+
+    def local_search_all(n, keys):
+        store.search_batch_device(queries_ptr(), n, dim, k, mask_ptr(), ws.data_ptr(), keys.data_ptr(), stream())
+
+    def merge(gathered, world, n_queries, kk):
+        ctx.merge_topk_batch_device(gathered.data_ptr(), world, batch * kk, n_queries, kk, kk,
+                                    abi.VS_ANGULAR, out_ids.data_ptr(), out_dist.data_ptr(),
+                                    out_n.data_ptr(), stream())
+        return out_ids, out_dist, out_n
+
+    s = ShardedSearch(None, merge, k, batch, device, group, local_search_all=local_search_all)
     s.workspace = ws  # keep alive
     return s

@@ -22,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n_docs, dim, k, batch, out_dir):
+def _worker(rank, world, port, n_docs, dim, k, batch, out_dir, all_at_once=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -49,7 +49,14 @@ def _worker(rank, world, port, n_docs, dim, k, batch, out_dir):
                 out.append(sharded.unpack_keys(np.sort(g[:, q, :].reshape(-1))[:kk]))
             return out
 
-        s = sharded.ShardedSearch(local_search, merge, k, batch, torch.device("cpu"))
+        def local_search_all(n, keys):  # the batched form: every query of the step in one call
+            for j in range(n):
+                local_search(j, keys[j * k:(j + 1) * k])
+
+        if all_at_once:
+            s = sharded.ShardedSearch(None, merge, k, batch, torch.device("cpu"), local_search_all=local_search_all)
+        else:
+            s = sharded.ShardedSearch(local_search, merge, k, batch, torch.device("cpu"))
         results = s.run()
         if rank == 0:
             np.savez(os.path.join(out_dir, "result.npz"),
@@ -58,11 +65,12 @@ def _worker(rank, world, port, n_docs, dim, k, batch, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_docs", [(2, 1000), (3, 1000), (2, 70)])
-def test_sharded_search_equals_single_store(tmp_path, world, n_docs):
+@pytest.mark.parametrize("world,n_docs,all_at_once", [(2, 1000, False), (3, 1000, False), (2, 70, False),
+                                                      (2, 1000, True)])
+def test_sharded_search_equals_single_store(tmp_path, world, n_docs, all_at_once):
     from oracle import scan as oracle
     dim, k, batch = 32, 10, 4
-    mp.spawn(_worker, args=(world, _free_port(), n_docs, dim, k, batch, str(tmp_path)), nprocs=world,
+    mp.spawn(_worker, args=(world, _free_port(), n_docs, dim, k, batch, str(tmp_path), all_at_once), nprocs=world,
              join=True)
     got = np.load(tmp_path / "result.npz")
     vectors = synthetic_vectors(n_docs, dim, 0xC0FFEE)
