@@ -403,6 +403,41 @@ def test_masks_kept_on_the_device(gpu_ctx):
         other.destroy()
 
 
+def test_concurrent_searches_from_many_threads(gpu_ctx):
+    """The reference shares one Index between request threads (search is synchronous per thread);
+    vs_search* must be re-entrant on a sealed store: every thread gets the single-threaded answer."""
+    import threading
+    n, dim, k = 40000, 128, 10
+    vectors = synthetic_vectors(n, dim, 301)
+    queries = synthetic_vectors(48, dim, 302)
+    mask = facet_mask(n, 10)
+    store = make_store(gpu_ctx, vectors)
+    kept = store.create_mask(mask)
+    try:
+        want = [store.search(q, k, mask) for q in queries]
+        errors = []
+
+        def work(t):
+            try:
+                for rep in range(3):
+                    for j in range(t, len(queries), 8):
+                        for got in (store.search(queries[j], k, mask), store.search_mask(queries[j], k, kept)):
+                            if got[0].tolist() != want[j][0].tolist() or got[1].tolist() != want[j][1].tolist():
+                                errors.append((t, j))
+            except Exception as e:  # noqa: BLE001
+                errors.append((t, repr(e)))
+
+        threads = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        assert not errors, errors[:5]
+    finally:
+        store.destroy_mask(kept)
+        store.destroy()
+
+
 def test_device_api_and_shard_merge(gpu_ctx):
     """Two docid-range shards searched through the device entry point, keys
     concatenated as an all-gather would, merged: identical to one store."""
