@@ -97,6 +97,15 @@ int32_t vs_set_scan_tuning(vs_ctx* ctx, int32_t blocks, int32_t nt);
 int32_t vs_store_create(vs_ctx* ctx, uint16_t store_index, uint32_t dim, int32_t dtype,
                         int32_t metric, uint32_t docid_base, uint64_t capacity, vs_store** out);
 
+/* Grows a store to `capacity` slots (no-op when it is not larger); contents, the
+ * sealed state and the dirty state are kept. milli hands out ever larger internal
+ * docids as an index grows (src/update/available_documents_ids.rs); the indexer
+ * calls this before `add_item`s beyond the current capacity
+ * (src/update/index_documents/typed_chunk.rs:650,691). Needs exclusion from every
+ * other call on the store, searches included; masks made for the store before
+ * the call are refused afterwards and must be created again. */
+int32_t vs_store_reserve(vs_store* s, uint64_t capacity);
+
 /* Looks a store up by index. Replaces Context::vector_reader(index) =
  * arroy::Reader::open (src/search/context.rs:188-190): a store that does not
  * exist or was never sealed yields VS_E_NO_STORE, as Reader::open yields

@@ -41,6 +41,7 @@ SIGNATURES = {
     "vs_store_upload": [_vp, _u32p, _f32p, _u64],
     "vs_store_upload_device": [_vp, _u32, _vp, _u64, _vp],
     "vs_store_remove": [_vp, _u32p, _u64],
+    "vs_store_reserve": [_vp, _u64],
     "vs_store_seal": [_vp],
     "vs_store_destroy": [_vp],
     "vs_store_len": [_vp, _u64p],
@@ -194,6 +195,9 @@ class Store:
     def remove(self, docids):
         docids = np.ascontiguousarray(docids, np.uint32)
         self._ck(lib.vs_store_remove(self.handle, _ptr(docids, _u32p), docids.size))
+
+    def reserve(self, capacity):
+        self._ck(lib.vs_store_reserve(self.handle, capacity))
 
     def seal(self):
         self._ck(lib.vs_store_seal(self.handle))

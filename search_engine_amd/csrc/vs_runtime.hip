@@ -99,6 +99,7 @@ struct vs_ctx {
 struct vs_mask {
     vs_store* store;
     uint64_t* d_words;  // store->n_slots / 64 words, aligned with the store
+    uint64_t n_slots;   // of the store when the mask was made (vs_store_reserve outdates it)
 };
 
 struct vs_store {
@@ -513,6 +514,60 @@ extern "C" int32_t vs_store_create(vs_ctx* ctx, uint16_t store_index, uint32_t d
     return VS_OK;
 }
 
+extern "C" int32_t vs_store_reserve(vs_store* s, uint64_t capacity) {
+    if (int32_t rc = check_store(s)) return rc;
+    if (capacity <= s->capacity) return VS_OK;
+    if ((uint64_t)s->docid_base + capacity > (1ull << 32))
+        return fail(VS_E_INVALID_ARG, "docid range [%u, %u + %llu) does not fit u32 docids", s->docid_base,
+                    s->docid_base, (unsigned long long)capacity);
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    HIP_TRY(hipDeviceSynchronize());  // nothing of this store is in flight (the caller's side of the contract)
+    const uint64_t old_slots = s->n_slots, new_slots = (capacity + 63) / 64 * 64;
+    const size_t rb = s->row_bytes(), old_words = old_slots / 64, new_words = new_slots / 64;
+    void* rows = nullptr;
+    float* norms = nullptr;
+    uint64_t* present[2] = {nullptr, nullptr};
+    auto body = [&]() -> int32_t {
+        HIP_TRY(hipMalloc(&rows, (size_t)(new_slots + vs::SLAB_PAD_ROWS) * rb));
+        HIP_TRY(hipMemcpy(rows, s->d_rows, (size_t)old_slots * rb, hipMemcpyDeviceToDevice));
+        HIP_TRY(hipMemset(static_cast<unsigned char*>(rows) + (size_t)old_slots * rb, 0,
+                          (size_t)(new_slots - old_slots + vs::SLAB_PAD_ROWS) * rb));
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(hipMalloc(&present[i], new_words * 8));
+            HIP_TRY(hipMemcpy(present[i], s->d_present[i], old_words * 8, hipMemcpyDeviceToDevice));
+            HIP_TRY(hipMemset(present[i] + old_words, 0, (new_words - old_words) * 8));
+        }
+        if (s->d_norms) {
+            HIP_TRY(hipMalloc(&norms, (size_t)new_slots * 4));
+            HIP_TRY(hipMemcpy(norms, s->d_norms, (size_t)old_slots * 4, hipMemcpyDeviceToDevice));
+            HIP_TRY(hipMemset(norms + old_slots, 0, (size_t)(new_slots - old_slots) * 4));
+        }
+        HIP_TRY(hipDeviceSynchronize());
+        return VS_OK;
+    };
+    if (int32_t rc = body()) {
+        if (rows) (void)hipFree(rows);
+        if (norms) (void)hipFree(norms);
+        for (int i = 0; i < 2; ++i)
+            if (present[i]) (void)hipFree(present[i]);
+        return rc;
+    }
+    (void)hipFree(s->d_rows);
+    s->d_rows = rows;
+    if (s->d_norms) {
+        (void)hipFree(s->d_norms);
+        s->d_norms = norms;
+    }
+    for (int i = 0; i < 2; ++i) {
+        (void)hipFree(s->d_present[i]);
+        s->d_present[i] = present[i];
+    }
+    s->h_present.resize(new_words, 0);
+    s->capacity = capacity;
+    s->n_slots = new_slots;
+    return VS_OK;
+}
+
 extern "C" int32_t vs_store_open(vs_ctx* ctx, uint16_t store_index, vs_store** out) {
     if (!ctx || !out) return fail(VS_E_INVALID_ARG, "null context or out pointer");
     *out = nullptr;
@@ -755,7 +810,7 @@ int32_t mask_new(vs_store* s, vs_mask** out, std::unique_ptr<vs_mask>* m) {
     if (!out) return fail(VS_E_INVALID_ARG, "null out pointer");
     *out = nullptr;
     if (int32_t rc = check_store(s)) return rc;
-    m->reset(new vs_mask{s, nullptr});
+    m->reset(new vs_mask{s, nullptr, s->n_slots});
     HIP_TRY(hipSetDevice(s->ctx->device));
     if (hipMalloc(&(*m)->d_words, (size_t)(s->n_slots / 64) * 8) != hipSuccess)
         return fail(VS_E_OOM, "cannot allocate a %llu-byte mask", (unsigned long long)(s->n_slots / 8));
@@ -832,6 +887,8 @@ extern "C" int32_t vs_search_mask(vs_store* s, const float* query, uint32_t dim,
     if (int32_t rc = begin_search(s, query, dim, k, out_ids, out_dist, out_n)) return rc;
     *out_n = 0;
     if (mask && mask->store != s) return fail(VS_E_INVALID_ARG, "the mask was created for another store");
+    if (mask && mask->n_slots != s->n_slots)
+        return fail(VS_E_INVALID_ARG, "the mask was created before the store grew: create it again");
     if (k == 0) return VS_OK;
     std::unique_ptr<Workspace> ws;
     if (int32_t rc = ws_acquire(s->ctx, &ws)) return rc;

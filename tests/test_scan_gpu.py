@@ -403,6 +403,50 @@ def test_masks_kept_on_the_device(gpu_ctx):
         other.destroy()
 
 
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+def test_store_grows(gpu_ctx, dtype_name):
+    """vs_store_reserve: contents and the sealed state survive, new docids fit afterwards, masks
+    made for the smaller store are refused."""
+    from search_engine_amd import abi
+    dtype = abi.VS_F32 if dtype_name == "f32" else abi.VS_BF16
+    dim, base = 64, 128
+    vectors = synthetic_vectors(5000, dim, 401)
+    if dtype_name == "bf16":
+        vectors = oracle.bf16_round(vectors)
+    q = synthetic_vectors(1, dim, 402)[0]
+    docids = np.arange(5000, dtype=np.uint32) + base
+    store = make_store(gpu_ctx, vectors[:1000], docids[:1000], dtype=dtype, capacity=1000, docid_base=base)
+    old_mask = store.create_mask(facet_mask(base + 1000, 50))
+    try:
+        before = store.search(q, 10)
+        with pytest.raises(abi.VsError) as e:
+            store.upload(docids[3000:3001], vectors[3000:3001])
+        assert e.value.code == abi.VS_E_CAPACITY
+        store.reserve(500)   # not larger: nothing happens
+        store.reserve(5000)
+        after = store.search(q, 10)
+        assert after[0].tolist() == before[0].tolist() and after[1].tolist() == before[1].tolist()
+        with pytest.raises(abi.VsError) as e:
+            store.search_mask(q, 10, old_mask)
+        assert e.value.code == abi.VS_E_INVALID_ARG
+        store.upload(docids[3000:5000], vectors[3000:5000])
+        store.seal()
+        keep = np.r_[0:1000, 3000:5000]
+        mask = facet_mask(base + 5000, 50)
+        run_case(gpu_ctx, vectors[keep], q, 20, mask=mask, docids=docids[keep], docid_base=base, store=store)
+        if dtype_name == "bf16":  # the batched scan reads whole 256-row tiles of the new slab
+            got = store.search_batch(np.stack([q, -q]), 10, mask)
+            for qq, (ids, dist) in zip((q, -q), got):
+                s_ids, _ = store.search(oracle.bf16_round(qq[None])[0], 10, mask)
+                assert ids.tolist() == s_ids.tolist()
+        with pytest.raises(abi.VsError) as e:
+            store.upload(np.array([base + 5000], np.uint32), vectors[:1])
+        assert e.value.code == abi.VS_E_CAPACITY
+    finally:
+        store.destroy_mask(old_mask)
+        store.destroy()
+
+
 def test_concurrent_searches_from_many_threads(gpu_ctx):
     """The reference shares one Index between request threads (search is synchronous per thread);
     vs_search* must be re-entrant on a sealed store: every thread gets the single-threaded answer."""
