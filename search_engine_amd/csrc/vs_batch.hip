@@ -211,6 +211,7 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
                     --pos;
                 }
                 lists[pos * BN + tid] = key;
+                if (my_cnt < k) return;  // the list is not full: its k-th entry, hence tau, has not moved
                 kth = lists[(k - 1) * BN + tid];
             }
             const uint64_t my_bound = sbound[tid];
