@@ -49,3 +49,14 @@ def test_no_cpu_fallback_without_a_device():
 def test_host_binding_imports():
     from search_engine_amd import _host
     assert _host.distribution_shift(0.85, 0.1, 1.0) == 1.0
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: the header compiles as C99 on its own, with no C++ or HIP types."""
+    import subprocess
+    src = tmp_path / "use_abi.c"
+    src.write_text('#include "vs_abi.h"\n'
+                   "int probe(void) { vs_store *s = 0; vs_ctx *c = 0; vs_mask *m = 0;\n"
+                   "  return (s == 0) + (c == 0) + (m == 0) + VS_MAX_K; }\n")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only",
+                    "-I", os.path.join(ROOT, "include"), str(src)], check=True)
