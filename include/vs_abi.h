@@ -57,8 +57,14 @@ enum {
 /* Element type of a store's rows in HBM. */
 enum { VS_F32 = 0, VS_BF16 = 1, VS_BIN1 = 2 };
 /* Distance. VS_ANGULAR is arroy::distances::Angular (src/index.rs:155), the only
- * metric of the reference; VS_HAMMING exists for binary-quantised stores. */
-enum { VS_ANGULAR = 0, VS_HAMMING = 1 };
+ * metric of the reference. The others have no counterpart there:
+ *   VS_HAMMING    binary-quantised stores (VS_BIN1): popcount(row XOR query);
+ *   VS_EUCLIDEAN  f32/bf16 stores, as arroy's Euclidean: results ordered by the
+ *                 squared distance, reported distance = its square root;
+ *   VS_DOT        f32/bf16 stores, as arroy's DotProduct on a built index: results
+ *                 ordered by descending <row, query>, reported "distance" = that
+ *                 product. Ties break by ascending docid under every metric. */
+enum { VS_ANGULAR = 0, VS_HAMMING = 1, VS_EUCLIDEAN = 2, VS_DOT = 3 };
 
 /* Sentinel key that pads device-side key lists (see vs_search_device). */
 #define VS_KEY_NONE 0xFFFFFFFFFFFFFFFFull
@@ -224,7 +230,8 @@ int32_t vs_search_batch_device(vs_store* s, const float* d_queries, uint32_t n_q
 /* Merges `n_lists` ascending key lists of `k` entries each (list i at
  * d_keys + i * k; e.g. the all-gathered shard results) into the global top-k
  * and decodes it: d_out_ids[k], d_out_dist[k], *d_out_n. `metric` selects how a
- * key's distance field is decoded (VS_ANGULAR: f32; VS_HAMMING: integer as f32). */
+ * key's distance field is decoded (VS_ANGULAR: f32; VS_HAMMING: integer as f32;
+ * VS_EUCLIDEAN: square root of the f32; VS_DOT: the f32 negated). */
 int32_t vs_merge_topk_device(vs_ctx* ctx, const uint64_t* d_keys, uint32_t n_lists, uint32_t k,
                              int32_t metric, uint32_t* d_out_ids, float* d_out_dist,
                              uint32_t* d_out_n, void* hip_stream);

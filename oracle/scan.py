@@ -53,6 +53,10 @@ def lib():
         L.oracle_hamming_topk.argtypes = [
             _u64p, _u32p, ctypes.c_uint64, ctypes.c_uint32, _u64p, ctypes.c_uint32, _u64p,
             ctypes.c_uint64, _u32p, _u32p]
+        L.oracle_nns_by_vector_metric.restype = ctypes.c_uint32
+        L.oracle_nns_by_vector_metric.argtypes = [
+            _f32p, _u32p, ctypes.c_uint64, ctypes.c_uint32, _f32p, ctypes.c_uint32, _u64p,
+            ctypes.c_uint64, ctypes.c_int, ctypes.c_int, _u32p, _f32p]
         L.oracle_angular_distance.restype = ctypes.c_float
         L.oracle_angular_distance.argtypes = [ctypes.c_float] * 3
         _lib = L
@@ -130,6 +134,37 @@ def hamming_topk(codes, query, count, docids=None, mask=None):
                                   count, _p(mask, _u64p), 0 if mask is None else mask.size,
                                   _p(ids, _u32p), _p(dist, _u32p))
     return ids[:m].copy(), dist[:m].copy()
+
+
+METRIC_EUCLIDEAN, METRIC_DOT = 2, 3
+
+
+def nns_by_vector_metric(vectors, query, count, metric, docids=None, mask=None, mode=ACC_F32_SEQ):
+    """Exhaustive top-`count` under arroy's Euclidean or DotProduct (no counterpart in the
+    reference, which has Angular stores only: src/index.rs:155). Returns (ids, reported
+    distances): Euclidean = sqrt of the squared distance the results are ordered by; dot =
+    the product itself, results in descending order of it."""
+    vectors = _c(vectors, np.float32)
+    query = _c(query, np.float32)
+    docids = _c(docids, np.uint32)
+    mask = _c(mask, np.uint64)
+    n, dim = vectors.shape
+    ids = np.zeros(max(count, 1), np.uint32)
+    dist = np.zeros(max(count, 1), np.float32)
+    m = lib().oracle_nns_by_vector_metric(
+        _p(vectors, _f32p), _p(docids, _u32p), n, dim, _p(query, _f32p), count, _p(mask, _u64p),
+        0 if mask is None else mask.size, metric, mode, _p(ids, _u32p), _p(dist, _f32p))
+    return ids[:m].copy(), dist[:m].copy()
+
+
+def np_metric_f64(vectors, query, metric):
+    """Reported distance of every row in float64 (numpy restatement of the function above)."""
+    v = np.asarray(vectors, np.float64)
+    q = np.asarray(query, np.float64)
+    if metric == METRIC_DOT:
+        return v @ q
+    diff = v - q
+    return np.sqrt((diff * diff).sum(1))
 
 
 # ---- independent numpy restatement ------------------------------------------------------

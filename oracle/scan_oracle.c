@@ -257,3 +257,58 @@ uint32_t oracle_hamming_topk(const uint64_t* codes, const uint32_t* docids, uint
     free(all);
     return m;
 }
+
+/*
+ * Euclidean and dot-product stores have no counterpart in the reference either
+ * (src/index.rs:155 again); they follow the arroy 0.2.0 distances of the same
+ * name as published (distance/euclidean.rs, distance/dot_product.rs):
+ *   Euclidean   built_distance = sum (p_i - q_i)^2, results ordered by it,
+ *               reported distance = normalized_distance = its square root;
+ *   DotProduct  built_distance on a built index = -dot(p, q), results ordered by
+ *               it, reported distance = normalized_distance = dot(p, q).
+ * Ties break by ascending id as everywhere else. f32 accumulation left to right,
+ * or f64 (mode ACC_F64) rounded once. PARITY UNPINNED like the rest of this file.
+ */
+enum { METRIC_EUCLIDEAN = 2, METRIC_DOT = 3 };
+
+static float order_value(const float* p, const float* q, uint32_t n, int metric, int mode) {
+    if (metric == METRIC_DOT) return -dot_mode(p, q, n, mode);
+    if (mode == ACC_F64) {
+        double s = 0.0;
+        for (uint32_t i = 0; i < n; ++i) {
+            const double d = (double)p[i] - (double)q[i];
+            s += d * d;
+        }
+        return (float)s;
+    }
+    float s = 0.0f;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float d = p[i] - q[i];
+        s += d * d;
+    }
+    return s;
+}
+
+uint32_t oracle_nns_by_vector_metric(const float* vectors, const uint32_t* docids, uint64_t n_items,
+                                     uint32_t dim, const float* query, uint32_t count,
+                                     const uint64_t* mask, uint64_t n_mask_words, int metric,
+                                     int mode, uint32_t* out_ids, float* out_dist) {
+    if (count == 0 || (metric != METRIC_EUCLIDEAN && metric != METRIC_DOT)) return 0;
+    hit_t* all = (hit_t*)malloc((size_t)(n_items ? n_items : 1) * sizeof(hit_t));
+    uint64_t n = 0;
+    for (uint64_t i = 0; i < n_items; ++i) {
+        const uint32_t id = docids ? docids[i] : (uint32_t)i;
+        if (!is_candidate(id, mask, n_mask_words)) continue;
+        all[n].d = order_value(vectors + i * dim, query, dim, metric, mode);
+        all[n].id = id;
+        ++n;
+    }
+    qsort(all, n, sizeof(hit_t), hit_cmp);
+    const uint32_t m = n < count ? (uint32_t)n : count;
+    for (uint32_t i = 0; i < m; ++i) {
+        out_ids[i] = all[i].id;
+        out_dist[i] = metric == METRIC_DOT ? -all[i].d : sqrtf(all[i].d);
+    }
+    free(all);
+    return m;
+}

@@ -13,7 +13,7 @@ import numpy as np
 VS_OK, VS_E_INVALID_ARG, VS_E_DIM_MISMATCH, VS_E_NO_STORE, VS_E_DEVICE = 0, 1, 2, 3, 4
 VS_E_NOT_SEALED, VS_E_OOM, VS_E_CAPACITY, VS_E_FORMAT = 5, 6, 7, 8
 VS_F32, VS_BF16, VS_BIN1 = 0, 1, 2
-VS_ANGULAR, VS_HAMMING = 0, 1
+VS_ANGULAR, VS_HAMMING, VS_EUCLIDEAN, VS_DOT = 0, 1, 2, 3
 VS_KEY_NONE = 0xFFFFFFFFFFFFFFFF
 VS_MAX_K = 1024
 

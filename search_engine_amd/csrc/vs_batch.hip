@@ -610,7 +610,7 @@ hipError_t launch_scan_batch_bf16(const SlabView& s, const float* d_queries, uin
                                   const uint64_t* cand, uint32_t k, void* workspace,
                                   uint64_t* out_keys, uint32_t* out_ids, float* out_dist,
                                   uint32_t* out_n, hipStream_t stream) {
-    if (s.dtype != VS_BF16 || k == 0 || k > VS_BATCH_MAX_K || n_q == 0 || n_q > (uint32_t)BN ||
+    if (s.dtype != VS_BF16 || s.metric != VS_ANGULAR || k == 0 || k > VS_BATCH_MAX_K || n_q == 0 || n_q > (uint32_t)BN ||
         (s.n_slots & 63) != 0 || s.n_slots == 0)
         return hipErrorInvalidValue;
     const BatchPlan p = plan_batch(s, k);

@@ -14,13 +14,14 @@ constexpr uint32_t SLAB_PAD_ROWS = 192;  // readable rows behind the last slot (
 
 struct SlabView {
     const void* rows;         // (n_slots + SLAB_PAD_ROWS) * row_vecs * 16 bytes
-    const float* norms;       // n_slots (angular stores), ‖row‖₂
+    const float* norms;       // n_slots, ‖row‖₂ (angular stores; null otherwise)
     const uint64_t* present;  // n_slots / 64 words, bit set = slot holds an item
     uint64_t n_slots;
     uint32_t row_vecs;    // 16-byte vectors per row
     uint32_t dim;         // logical dimension (elements, or bits for bin1)
     uint32_t docid_base;  // multiple of 64
     int32_t dtype;        // VS_F32 / VS_BF16 / VS_BIN1
+    int32_t metric = 0;   // VS_ANGULAR / VS_EUCLIDEAN / VS_DOT (f32, bf16 rows), VS_HAMMING (bin1)
 };
 
 // Scan tuning knobs (0 = library default); exposed so the benchmark can A/B
@@ -35,17 +36,18 @@ uint32_t scan_grid_blocks(const SlabView& s, const ScanTuning& t, bool masked);
 // device bytes of the partial-list buffer one scan of this slab writes
 uint64_t scan_partial_bytes(const SlabView& s, uint32_t k, const ScanTuning& t);
 
-// Angular scan of one query (f32 or bf16 rows): writes the per-workgroup top-k
-// lists to `partial` and then the merged ascending top-k keys to `out_keys[k]`
-// (nullable) and, decoded, to out_ids / out_dist / out_n (nullable as a group).
-// `cand` (nullable) is aligned with `present`.
-hipError_t launch_scan_angular(const SlabView& s, const float* d_query, const uint64_t* cand,
+// Scan of one query over f32 or bf16 rows under s.metric (angular, Euclidean or
+// dot product): writes the per-workgroup top-k lists to `partial` and then the
+// merged ascending top-k keys to `out_keys[k]` (nullable) and, decoded, to
+// out_ids / out_dist / out_n (nullable as a group). `cand` (nullable) is aligned
+// with `present`.
+hipError_t launch_scan_float(const SlabView& s, const float* d_query, const uint64_t* cand,
                                uint32_t k, uint64_t* partial, uint64_t* out_keys,
                                uint32_t* out_ids, float* out_dist, uint32_t* out_n,
                                const ScanTuning& t, hipStream_t stream);
 
 // Hamming scan of one query against a VS_BIN1 slab. `d_query` holds the packed
-// query bits, row_vecs * 16 bytes, zero padded. Outputs as launch_scan_angular;
+// query bits, row_vecs * 16 bytes, zero padded. Outputs as launch_scan_float;
 // a key's distance field is the integer Hamming distance.
 hipError_t launch_scan_hamming(const SlabView& s, const void* d_query, const uint64_t* cand,
                                uint32_t k, uint64_t* partial, uint64_t* out_keys,

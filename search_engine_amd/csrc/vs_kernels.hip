@@ -41,6 +41,7 @@ struct ScanArgs {
     uint32_t dim;
     uint32_t docid_base;
     uint32_t k;
+    int32_t metric;  // host-side dispatch only
 };
 
 __device__ __forceinline__ uint32_t lanes_below(uint64_t m) {
@@ -64,6 +65,26 @@ __device__ __forceinline__ float dot_vec(u32x4 x, const float* q, float acc) {
         for (int j = 0; j < 4; ++j) {
             acc = __builtin_fmaf(__uint_as_float(x[j] << 16), q[2 * j], acc);
             acc = __builtin_fmaf(__uint_as_float(x[j] & 0xFFFF0000u), q[2 * j + 1], acc);
+        }
+    }
+    return acc;
+}
+// acc += ‖vector − query slice‖² (differences rounded to f32, then fused into the sum).
+template <int ELEM>
+__device__ __forceinline__ float sqdiff_vec(u32x4 x, const float* q, float acc) {
+    if (ELEM == VS_F32) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = __uint_as_float(x[j]) - q[j];
+            acc = __builtin_fmaf(d, d, acc);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lo = __uint_as_float(x[j] << 16) - q[2 * j];
+            const float hi = __uint_as_float(x[j] & 0xFFFF0000u) - q[2 * j + 1];
+            acc = __builtin_fmaf(lo, lo, acc);
+            acc = __builtin_fmaf(hi, hi, acc);
         }
     }
     return acc;
@@ -189,9 +210,15 @@ __device__ __forceinline__ void finish_block(WaveTopK& top, unsigned char* smem,
     }
 }
 
-template <int ELEM, int NCH, int U, bool NT>
-__global__ __launch_bounds__(WAVES * 64) void scan_angular_kernel(ScanArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// One query against every candidate row of an f32 or bf16 slab. METRIC picks what
+// a row's sort key is made of:
+//   VS_ANGULAR    arroy's Angular distance (above);
+//   VS_EUCLIDEAN  the SQUARED distance Σ(p − q)², as arroy's Euclidean orders its
+//                 results; the merge reports its square root (normalized_distance);
+//   VS_DOT        −⟨p, q⟩, so that larger products come first, as arroy's DotProduct
+//                 orders once an index is built; the merge reports ⟨p, q⟩.
+template <int METRIC, int ELEM, int NCH, int U, bool NT>
+__device__ __forceinline__ void scan_float_rows(const ScanArgs& a, unsigned char* smem) {
     constexpr int EPV = Epv<ELEM>::value;
     const int lane = threadIdx.x & 63;
     const uint32_t wib = uniform_u32(threadIdx.x >> 6);
@@ -241,15 +268,19 @@ __global__ __launch_bounds__(WAVES * 64) void scan_angular_kernel(ScanArgs a) {
                     x[u][c] = u32x4{0u, 0u, 0u, 0u};
                 }
             }
-            pn[u] = a.norms[slot[u]];
+            pn[u] = METRIC == VS_ANGULAR ? a.norms[slot[u]] : 0.0f;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float acc = 0.0f;
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) acc = dot_vec<ELEM>(x[u][c], q[c], acc);
+            for (int c = 0; c < NCH; ++c)
+                acc = METRIC == VS_EUCLIDEAN ? sqdiff_vec<ELEM>(x[u][c], q[c], acc)
+                                             : dot_vec<ELEM>(x[u][c], q[c], acc);
             const float pq = wave_sum_f32(acc);
-            const float d = angular_distance(pq, pn[u], qn);
+            const float d = METRIC == VS_ANGULAR     ? angular_distance(pq, pn[u], qn)
+                            : METRIC == VS_EUCLIDEAN ? pq
+                                                     : -pq;
             const uint64_t key = make_key(uniform_u32(f32_orderable(d)), a.docid_base + slot[u]);
             if ((uint32_t)u < nvalid && key < top.tau) top.insert(key);
         }
@@ -257,6 +288,24 @@ __global__ __launch_bounds__(WAVES * 64) void scan_angular_kernel(ScanArgs a) {
 
     scan_masked_slots<U>(a.present, a.cand, a.n_slots, w, W, lane, queue, score_rows);
     finish_block(top, smem, k, wib, lane, a.partial);
+}
+
+template <int ELEM, int NCH, int U, bool NT>
+__global__ __launch_bounds__(WAVES * 64) void scan_angular_kernel(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    scan_float_rows<VS_ANGULAR, ELEM, NCH, U, NT>(a, smem);
+}
+// The two metrics below have no counterpart in the reference (its stores are all
+// Angular, src/index.rs:155); they follow the arroy distances of the same name.
+template <int ELEM, int NCH, int U>
+__global__ __launch_bounds__(WAVES * 64) void scan_euclidean_kernel(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    scan_float_rows<VS_EUCLIDEAN, ELEM, NCH, U, true>(a, smem);
+}
+template <int ELEM, int NCH, int U>
+__global__ __launch_bounds__(WAVES * 64) void scan_dot_kernel(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    scan_float_rows<VS_DOT, ELEM, NCH, U, true>(a, smem);
 }
 
 // ---- Hamming scan of binary-quantised rows ----------------------------------------------
@@ -505,9 +554,14 @@ __global__ __launch_bounds__(256) void merge_kernel(const uint64_t* keys, uint32
                 if (out_ids) {
                     const uint32_t hi = (uint32_t)(key >> 32);
                     out_ids[i] = (uint32_t)key;
-                    out_dist[i] = key == KEY_NONE ? 0.0f
-                                  : metric == VS_HAMMING ? (float)hi
-                                                         : f32_from_orderable(hi);
+                    float d = 0.0f;
+                    if (key != KEY_NONE) {
+                        if (metric == VS_HAMMING) d = (float)hi;
+                        else if (metric == VS_EUCLIDEAN) d = sqrtf(f32_from_orderable(hi));
+                        else if (metric == VS_DOT) d = -f32_from_orderable(hi);
+                        else d = f32_from_orderable(hi);
+                    }
+                    out_dist[i] = d;
                 }
             }
             n += (uint32_t)__popcll(__ballot(key != KEY_NONE));
@@ -629,7 +683,11 @@ template <int ELEM, int NCH, int U>
 static hipError_t launch_scan_t(const ScanArgs& a, uint32_t blocks, size_t lds, const ScanTuning& t,
                                 hipStream_t stream) {
     const dim3 grid(blocks), block(WAVES * 64);
-    if (t.nt)
+    if (a.metric == VS_EUCLIDEAN)
+        hipLaunchKernelGGL((scan_euclidean_kernel<ELEM, NCH, U>), grid, block, lds, stream, a);
+    else if (a.metric == VS_DOT)
+        hipLaunchKernelGGL((scan_dot_kernel<ELEM, NCH, U>), grid, block, lds, stream, a);
+    else if (t.nt)
         hipLaunchKernelGGL((scan_angular_kernel<ELEM, NCH, U, true>), grid, block, lds, stream, a);
     else
         hipLaunchKernelGGL((scan_angular_kernel<ELEM, NCH, U, false>), grid, block, lds, stream, a);
@@ -643,8 +701,10 @@ static hipError_t launch_scan_e(const ScanArgs& a, uint32_t blocks, size_t lds, 
     if (nch <= 1) return launch_scan_t<ELEM, 1, 8>(a, blocks, lds, t, stream);
     if (nch <= 2) return launch_scan_t<ELEM, 2, 8>(a, blocks, lds, t, stream);
     if (nch <= 3) {
-        if (t.rows_in_flight == 2) return launch_scan_t<ELEM, 3, 2>(a, blocks, lds, t, stream);
-        if (t.rows_in_flight == 8) return launch_scan_t<ELEM, 3, 8>(a, blocks, lds, t, stream);
+        if (a.metric == VS_ANGULAR) {  // schedule probes, angular only
+            if (t.rows_in_flight == 2) return launch_scan_t<ELEM, 3, 2>(a, blocks, lds, t, stream);
+            if (t.rows_in_flight == 8) return launch_scan_t<ELEM, 3, 8>(a, blocks, lds, t, stream);
+        }
         return launch_scan_t<ELEM, 3, 4>(a, blocks, lds, t, stream);
     }
     if (nch <= 4) return launch_scan_t<ELEM, 4, 4>(a, blocks, lds, t, stream);
@@ -655,7 +715,7 @@ static hipError_t launch_scan_e(const ScanArgs& a, uint32_t blocks, size_t lds, 
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_scan_angular(const SlabView& s, const float* d_query, const uint64_t* cand,
+hipError_t launch_scan_float(const SlabView& s, const float* d_query, const uint64_t* cand,
                                uint32_t k, uint64_t* partial, uint64_t* out_keys,
                                uint32_t* out_ids, float* out_dist, uint32_t* out_n,
                                const ScanTuning& t, hipStream_t stream) {
@@ -672,6 +732,10 @@ hipError_t launch_scan_angular(const SlabView& s, const float* d_query, const ui
     a.dim = s.dim;
     a.docid_base = s.docid_base;
     a.k = k;
+    a.metric = s.metric;
+    if (s.metric != VS_ANGULAR && s.metric != VS_EUCLIDEAN && s.metric != VS_DOT)
+        return hipErrorInvalidValue;
+    if (s.metric == VS_ANGULAR && !s.norms) return hipErrorInvalidValue;
     const uint32_t blocks = scan_grid_blocks(s, t, cand != nullptr);
     const size_t lds = (size_t)WAVES * k * 8 + (size_t)WAVES * QCAP * 4;
     hipError_t e;
@@ -682,7 +746,7 @@ hipError_t launch_scan_angular(const SlabView& s, const float* d_query, const ui
     else
         return hipErrorInvalidValue;
     if (e != hipSuccess) return e;
-    return launch_merge(partial, blocks, 1, blocks, k, VS_ANGULAR, out_keys, out_ids, out_dist,
+    return launch_merge(partial, blocks, 1, blocks, k, s.metric, out_keys, out_ids, out_dist,
                         out_n, stream);
 }
 

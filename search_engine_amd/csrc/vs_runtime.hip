@@ -131,6 +131,7 @@ struct vs_store {
         v.dim = dim;
         v.docid_base = docid_base;
         v.dtype = dtype;
+        v.metric = metric;
         return v;
     }
     uint64_t row_bytes() const { return (uint64_t)row_vecs * 16; }
@@ -207,7 +208,7 @@ int32_t begin_search(vs_store* s, const float* query, uint32_t dim, uint32_t k, 
     return VS_OK;
 }
 
-// One scan of a sealed store: angular for f32/bf16 rows, Hamming for bin1 rows.
+// One scan of a sealed store under its metric.
 int32_t launch_scan(vs_store* s, const void* d_query, const uint64_t* d_cand, uint32_t k,
                     uint64_t* d_partial, uint64_t* d_keys, uint32_t* d_ids, float* d_dist,
                     uint32_t* d_n, hipStream_t stream) {
@@ -217,7 +218,7 @@ int32_t launch_scan(vs_store* s, const void* d_query, const uint64_t* d_cand, ui
         HIP_TRY(vs::launch_scan_hamming(v, d_query, d_cand, k, d_partial, d_keys, d_ids, d_dist, d_n,
                                         t, stream));
     else
-        HIP_TRY(vs::launch_scan_angular(v, static_cast<const float*>(d_query), d_cand, k, d_partial,
+        HIP_TRY(vs::launch_scan_float(v, static_cast<const float*>(d_query), d_cand, k, d_partial,
                                         d_keys, d_ids, d_dist, d_n, t, stream));
     return VS_OK;
 }
@@ -467,8 +468,11 @@ extern "C" int32_t vs_store_create(vs_ctx* ctx, uint16_t store_index, uint32_t d
     if (dim == 0) return fail(VS_E_INVALID_ARG, "dimension 0");
     if (dtype != VS_F32 && dtype != VS_BF16 && dtype != VS_BIN1)
         return fail(VS_E_INVALID_ARG, "unknown element type %d", dtype);
+    if (metric != VS_ANGULAR && metric != VS_HAMMING && metric != VS_EUCLIDEAN && metric != VS_DOT)
+        return fail(VS_E_INVALID_ARG, "unknown metric %d", metric);
     if ((dtype == VS_BIN1) != (metric == VS_HAMMING))
-        return fail(VS_E_INVALID_ARG, "bin1 stores use VS_HAMMING, f32/bf16 stores VS_ANGULAR");
+        return fail(VS_E_INVALID_ARG,
+                    "bin1 stores use VS_HAMMING; f32/bf16 stores VS_ANGULAR, VS_EUCLIDEAN or VS_DOT");
     if (docid_base % 64) return fail(VS_E_INVALID_ARG, "docid_base must be a multiple of 64");
     if (capacity == 0 || (uint64_t)docid_base + capacity > (1ull << 32))
         return fail(VS_E_INVALID_ARG, "docid range [%u, %u + %llu) does not fit u32 docids", docid_base,
@@ -912,7 +916,7 @@ extern "C" int32_t vs_search_batch(vs_store* s, const float* queries, uint32_t n
         rc = stage_dense_mask(s, ws.get(), mask_words, n_mask_words);
         d_cand = ws->d_mask;
     }
-    if (rc == VS_OK && s->dtype == VS_BF16 && k <= VS_BATCH_MAX_K && n_q > 1) {
+    if (rc == VS_OK && s->dtype == VS_BF16 && s->metric == VS_ANGULAR && k <= VS_BATCH_MAX_K && n_q > 1) {
         rc = run_batch_and_fetch(s, ws.get(), queries, n_q, k, d_cand, out_ids, out_dist, out_n);
     } else if (rc == VS_OK) {
         rc = run_many_and_fetch(s, ws.get(), queries, n_q, k, d_cand, out_ids, out_dist, out_n);
@@ -949,7 +953,8 @@ extern "C" int32_t vs_search_device(vs_store* s, const void* d_query, uint32_t d
 
 extern "C" int32_t vs_search_batch_workspace_bytes(vs_store* s, uint32_t k, uint64_t* bytes) {
     if (!s || !bytes) return fail(VS_E_INVALID_ARG, "null argument");
-    if (s->dtype != VS_BF16) return fail(VS_E_INVALID_ARG, "the batched path needs a bf16 store");
+    if (s->dtype != VS_BF16 || s->metric != VS_ANGULAR)
+        return fail(VS_E_INVALID_ARG, "the batched path needs an angular bf16 store");
     if (k == 0 || k > VS_BATCH_MAX_K) return fail(VS_E_INVALID_ARG, "k = %u out of range", k);
     *bytes = vs::batch_workspace_bytes(s->view(), k);
     return VS_OK;
@@ -961,7 +966,8 @@ extern "C" int32_t vs_search_batch_device(vs_store* s, const float* d_queries, u
     if (int32_t rc = check_store(s)) return rc;
     if (!d_queries || !d_workspace || !d_out_keys) return fail(VS_E_INVALID_ARG, "null device buffer");
     if (!s->sealed.load()) return fail(VS_E_NOT_SEALED, "store %u was never sealed", s->index);
-    if (s->dtype != VS_BF16) return fail(VS_E_INVALID_ARG, "the batched path needs a bf16 store");
+    if (s->dtype != VS_BF16 || s->metric != VS_ANGULAR)
+        return fail(VS_E_INVALID_ARG, "the batched path needs an angular bf16 store");
     if (dim != s->dim) {
         g_dim_expected = s->dim;
         g_dim_received = dim;

@@ -113,3 +113,33 @@ def test_bf16_round_helper():
     r = oracle.bf16_round(x)
     assert r.dtype == np.float32 and np.all((r.view(np.uint32) & 0xFFFF) == 0)
     assert r[0] == 1.0 and r[1] == 1.0 and r[2] == np.float32(1.015625)  # ties to even
+
+
+@pytest.mark.parametrize("metric", [oracle.METRIC_EUCLIDEAN, oracle.METRIC_DOT])
+def test_euclidean_and_dot_oracle_matches_numpy(metric):
+    """The C restatement of arroy's Euclidean / DotProduct order against the numpy one
+    (float64), known answers first."""
+    v = np.array([[0, 1, 2], [6, 7, 8], [9, 10, 11], [0, -1, -2]], np.float32)
+    q = np.array([0, 1, 2], np.float32)
+    ids, dist = oracle.nns_by_vector_metric(v, q, 10, metric)
+    if metric == oracle.METRIC_EUCLIDEAN:
+        assert ids.tolist() == [0, 3, 1, 2]
+        np.testing.assert_allclose(dist, np.sqrt([0.0, 20.0, 108.0, 243.0]), rtol=1e-7)
+    else:
+        assert ids.tolist() == [2, 1, 0, 3] and dist.tolist() == [32.0, 23.0, 5.0, -5.0]
+    vectors = synthetic_vectors(3000, 96, seed=12)
+    query = synthetic_vectors(1, 96, seed=13)[0]
+    mask = facet_mask(3000, 30)
+    ok = oracle.mask_to_bool(mask, 3000)
+    f64 = oracle.np_metric_f64(vectors, query, metric)
+    order_key = -f64 if metric == oracle.METRIC_DOT else f64
+    expect = [i for i in np.argsort(order_key, kind="stable") if ok[i]][:20]
+    for mode in (oracle.ACC_F32_SEQ, oracle.ACC_F64):
+        ids, dist = oracle.nns_by_vector_metric(vectors, query, 20, metric, mask=mask, mode=mode)
+        assert ids.tolist() == expect
+        np.testing.assert_allclose(dist, f64[expect], rtol=1e-5, atol=1e-5)
+    # exact ties come out by ascending id; an empty filter gives nothing
+    twice = np.concatenate([vectors[:50], vectors[:50]])
+    ids, dist = oracle.nns_by_vector_metric(twice, query, 6, metric)
+    assert ids[0] + 50 == ids[1] and ids[2] + 50 == ids[3] and dist[0] == dist[1]
+    assert len(oracle.nns_by_vector_metric(vectors, query, 5, metric, mask=np.zeros(47, np.uint64))[0]) == 0

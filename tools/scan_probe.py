@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--dtype", default="f32")
+    ap.add_argument("--metric", default="", help="angular | euclidean | dot (f32/bf16 rows); default by dtype")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--reps", type=int, default=4)
     ap.add_argument("--pass-percents", default="100,10,1")
@@ -33,7 +34,9 @@ def main():
     tdtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
     binary = args.dtype == "bin1"
     store = ctx.create_store(0, args.dim, n, dtype=dtype,
-                             metric=abi.VS_HAMMING if binary else abi.VS_ANGULAR)
+                             metric=abi.VS_HAMMING if binary else
+                             {"": abi.VS_ANGULAR, "angular": abi.VS_ANGULAR, "euclidean": abi.VS_EUCLIDEAN,
+                              "dot": abi.VS_DOT}[args.metric])
     gen = torch.Generator(device=dev)
     gen.manual_seed(0xC0FFEE)
     stream = torch.cuda.current_stream().cuda_stream
@@ -58,7 +61,7 @@ def main():
     for p in [int(x) for x in args.pass_percents.split(",")]:
         mask = device_mask(0, n, p, dev)
         n_pass = int(lut[mask.view(torch.uint8).long()].sum().item())
-        algo = n_pass * (store.row_bytes + (0 if binary else 4)) + n // 8
+        algo = n_pass * (store.row_bytes + (4 if args.metric in ('', 'angular') and not binary else 0)) + n // 8
         times = {v: [] for v in variants}
         ref = None
         for r in range(args.rounds + 1):
