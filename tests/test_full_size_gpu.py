@@ -64,6 +64,37 @@ def compare(store, query, ids, dist, ref_ids, k, n_candidates):
     return check_hits(ids, dist, expected, d64, k, n_candidates)
 
 
+@pytest.mark.parametrize("k", [10, 100])
+def test_config2_1m_x_768_f32_against_the_cpu_oracle(gpu_ctx, k):
+    """BASELINE config 2 is small enough for the C oracle itself (one query per thread):
+    1 M x 768 f32, facet filters of 100 / 10 / 1 %."""
+    from conftest import facet_mask
+    from oracle import scan as oracle
+    n, dim = 1_000_000, 768
+    rng = np.random.default_rng(2024)
+    vectors = rng.standard_normal((n, dim), dtype=np.float32)
+    queries = rng.standard_normal((3, dim), dtype=np.float32)
+    docids = np.arange(n, dtype=np.uint32)
+    store = gpu_ctx.create_store(0x7004 + k, dim, n)
+    try:
+        for lo in range(0, n, 1 << 17):
+            store.upload(docids[lo:lo + (1 << 17)], vectors[lo:lo + (1 << 17)])
+        store.seal()
+        norms = oracle.norms(vectors)
+        for pass_percent in (100, 10, 1):
+            mask = facet_mask(n, pass_percent) if pass_percent < 100 else None
+            n_cand = n if mask is None else int(oracle.mask_to_bool(mask, n).sum())
+            o_ids, _, o_n, _ = oracle.nns_batch_mt(vectors, queries, k, mask=mask, norms=norms)
+            for j, q in enumerate(queries):
+                ids, dist = store.search(q, k, mask)
+                assert o_n[j] == k
+                cand = sorted(set(ids.tolist()) | set(o_ids[j].tolist()))
+                d64 = dict(zip(cand, oracle.all_distances_f64(vectors[cand], q).tolist()))
+                assert check_hits(ids, dist, o_ids[j], d64, k, n_cand) <= 2
+    finally:
+        store.destroy()
+
+
 @pytest.mark.parametrize("pass_percent", [100, 10])
 def test_headline_10m_x_768_f32(gpu_ctx, pass_percent):
     from search_engine_amd import abi
