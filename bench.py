@@ -84,9 +84,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # VS_BENCH_FORCE_DIST=1: a one-rank RCCL group, so that the multi-rank code (collectives
+    # included) can be rehearsed on a single GPU. Never set by the driver.
+    use_dist = world > 1 or os.environ.get("VS_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from search_engine_amd import abi
 
@@ -122,17 +127,17 @@ def main():
     row_bytes = store.row_bytes
     from search_engine_amd import sharded
     if args.batch_queries:
-        batched_bench(args, ctx, store, dev, stream, queries, first, n_slots, n_local, rank, world)
+        batched_bench(args, ctx, store, dev, stream, queries, first, n_slots, n_local, rank, world, use_dist)
         store.destroy()
         ctx.close()
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
     cur = {"step": 0, "mask": None, "events": None}
     searcher = sharded.gpu_sharded_search(
         ctx, store, k, qps_batch, dev,
         query_ptr=lambda j: queries[(cur["step"] * qps_batch + j) % 1024].data_ptr(),
-        mask_ptr=lambda: cur["mask"].data_ptr(), stream=lambda: stream)
+        mask_ptr=lambda: cur["mask"].data_ptr(), stream=lambda: stream, always_gather=use_dist)
     plain_local_search = searcher.local_search
 
     def timed_local_search(j, out_keys):
@@ -154,7 +159,7 @@ def main():
         out["ids"], out["dist"], out["n"] = searcher.run()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -177,7 +182,7 @@ def main():
             step(warmup + i, mask, events)
         barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -269,11 +274,11 @@ def main():
         print(json.dumps(line), flush=True)
     store.destroy()
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
-def batched_bench(args, ctx, store, dev, stream, queries, first, n_slots, n_local, rank, world):
+def batched_bench(args, ctx, store, dev, stream, queries, first, n_slots, n_local, rank, world, use_dist):
     """BASELINE config 3: `--batch-queries` queries per step against a bf16 store sharded over the
     ranks; one vs_search_batch_device per rank, one all-gather of the keys, one merge launch."""
     import torch.distributed as dist
@@ -285,10 +290,10 @@ def batched_bench(args, ctx, store, dev, stream, queries, first, n_slots, n_loca
     cur = {"step": 0}
     searcher = sharded.gpu_sharded_batch_search(
         ctx, store, k, b, dev, queries_ptr=lambda: queries[(cur["step"] * b) % (1024 - b + 1):].data_ptr(),
-        mask_ptr=lambda: mask.data_ptr(), stream=lambda: stream)
+        mask_ptr=lambda: mask.data_ptr(), stream=lambda: stream, always_gather=use_dist)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -302,7 +307,7 @@ def batched_bench(args, ctx, store, dev, stream, queries, first, n_slots, n_loca
         searcher.run()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())

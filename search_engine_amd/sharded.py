@@ -60,7 +60,8 @@ class ShardedSearch:
     exercise the sharding and the collective under gloo.
     """
 
-    def __init__(self, local_search, merge, k, batch, device, group=None, local_search_all=None):
+    def __init__(self, local_search, merge, k, batch, device, group=None, local_search_all=None,
+                 always_gather=False):
         self.local_search = local_search
         # optional: searches queries 0..n-1 in one go, keys[j*k:(j+1)*k] = query j (one pass over
         # the shard for all of them instead of one per query)
@@ -70,9 +71,12 @@ class ShardedSearch:
         self.batch = batch
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # always_gather: run the collective even in a one-rank group (a rehearsal of the
+        # multi-rank path on a single GPU)
+        self.gather = self.world > 1 or (always_gather and dist.is_initialized())
         self.keys = torch.empty(batch * k, dtype=torch.int64, device=device)
         self.gathered = (torch.empty(self.world * batch * k, dtype=torch.int64, device=device)
-                         if self.world > 1 else self.keys)
+                         if self.gather else self.keys)
 
     def run(self, n_queries=None):
         """Searches queries 0..n_queries-1 of the current batch (default: a full batch)."""
@@ -82,13 +86,13 @@ class ShardedSearch:
         else:
             for j in range(n):
                 self.local_search(j, self.keys[j * self.k:(j + 1) * self.k])
-        if self.world > 1:
+        if self.gather:
             dist.all_gather_into_tensor(self.gathered, self.keys, group=self.group)
         return self.merge(self.gathered, self.world, n, self.k)
 
 
 def gpu_sharded_search(ctx, store, k, batch, device, query_ptr, mask_ptr, stream, group=None,
-                       metric=0):
+                       metric=0, always_gather=False):
     """ShardedSearch over libvs_amd.so. query_ptr(j) -> device address of the j-th query of the
     current batch; mask_ptr -> device address of the shard-aligned candidate words (0 = none)."""
     from . import abi
@@ -107,12 +111,13 @@ def gpu_sharded_search(ctx, store, k, batch, device, query_ptr, mask_ptr, stream
                                     out_n.data_ptr(), stream())
         return out_ids, out_dist, out_n
 
-    s = ShardedSearch(local_search, merge, k, batch, device, group)
+    s = ShardedSearch(local_search, merge, k, batch, device, group, always_gather=always_gather)
     s.workspace = ws  # keep alive
     return s
 
 
-def gpu_sharded_batch_search(ctx, store, k, batch, device, queries_ptr, mask_ptr, stream, group=None):
+def gpu_sharded_batch_search(ctx, store, k, batch, device, queries_ptr, mask_ptr, stream, group=None,
+                             always_gather=False):
     """ShardedSearch whose local step is ONE vs_search_batch_device call (bf16 store, k <= 32,
     batch <= 256: the scan on the matrix cores). queries_ptr() -> device address of the batch's
     f32 queries [batch][dim]."""
@@ -132,6 +137,7 @@ def gpu_sharded_batch_search(ctx, store, k, batch, device, queries_ptr, mask_ptr
                                     out_n.data_ptr(), stream())
         return out_ids, out_dist, out_n
 
-    s = ShardedSearch(None, merge, k, batch, device, group, local_search_all=local_search_all)
+    s = ShardedSearch(None, merge, k, batch, device, group, local_search_all=local_search_all,
+                      always_gather=always_gather)
     s.workspace = ws  # keep alive
     return s
