@@ -244,12 +244,14 @@ int32_t run_and_fetch(vs_store* s, Workspace* ws, const float* h_query, uint32_t
         memcpy(ws->h_pinned, h_query, query_bytes);
     }
     HIP_TRY(hipMemcpyAsync(ws->d_query, ws->h_pinned, query_bytes, hipMemcpyHostToDevice, ws->stream));
-    if (int32_t rc = launch_scan(s, ws->d_query, d_cand, k, ws->d_partial, nullptr, ws->d_ids,
-                                 ws->d_dist, ws->d_n, ws->stream))
-        return rc;
     unsigned char* hr = ws->h_pinned + QUERY_BYTES;
-    // ids, distances and the count are contiguous on the device
-    HIP_TRY(hipMemcpyAsync(hr, ws->d_ids, (size_t)VS_MAX_K * 8 + 4, hipMemcpyDeviceToHost, ws->stream));
+    // The merge writes the k results straight into the pinned host block (it is mapped into
+    // the device's address space): no copy back, one wait.
+    if (int32_t rc = launch_scan(s, ws->d_query, d_cand, k, ws->d_partial, nullptr,
+                                 reinterpret_cast<uint32_t*>(hr),
+                                 reinterpret_cast<float*>(hr + (size_t)VS_MAX_K * 4),
+                                 reinterpret_cast<uint32_t*>(hr + (size_t)VS_MAX_K * 8), ws->stream))
+        return rc;
     HIP_TRY(hipStreamSynchronize(ws->stream));
     uint32_t n;
     memcpy(&n, hr + (size_t)VS_MAX_K * 8, 4);
