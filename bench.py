@@ -200,7 +200,8 @@ def main():
             sweep.append({"pass_percent": p, "qps": round(r["qps"], 2),
                           "scan_ms": round(r["scan_ms"], 4),
                           "achieved_gbps": round(r["achieved_gbps"], 1),
-                          "frac": round(r["achieved_gbps"] / HBM_PEAK_GBPS, 4)})
+                          "frac": round(r["achieved_gbps"] / HBM_PEAK_GBPS, 4),
+                          "algorithmic_bytes_per_launch": r["algo_bytes"]})
 
     # sanity: the last batch's results are well-formed (k hits, ascending)
     torch.cuda.synchronize()
@@ -227,14 +228,22 @@ def main():
         cpu = cpu_baseline(sample, queries, args, dim, k)
 
     if rank == 0:
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")
-        if os.path.exists(tpath):
+        def recorded_traffic(pass_percent):
+            """HBM bytes per scan launch from the committed rocprofv3 --pmc FETCH_SIZE pass of this
+            workload (profiles/scan_traffic*.json, written by tools/profile_summary.py), or None."""
+            sfx = "" if pass_percent == 100 else f"_p{pass_percent}"
+            tpath = os.path.join(ROOT, "profiles", f"scan_traffic{sfx}.json")
+            if not os.path.exists(tpath):
+                return None
             with open(tpath) as f:
                 t = json.load(f)
-            if t.get("docs") == args.docs and t.get("dtype") == args.dtype and t.get("n_gpus") == world \
-                    and t.get("pass_percent") == args.pass_percent:
-                traffic = t.get("hbm_bytes_per_launch")
+            same = (t.get("docs") == args.docs and t.get("dtype") == args.dtype and t.get("n_gpus") == world
+                    and t.get("pass_percent") == pass_percent)
+            return t.get("hbm_bytes_per_launch") if same else None
+
+        traffic = recorded_traffic(args.pass_percent)
+        for entry in sweep:
+            entry["traffic"] = recorded_traffic(entry["pass_percent"])
         line = {
             "metric": "filtered top-10 vector QPS, 10M×768, 1/2/4/8 GPUs; % of HBM roofline",
             "value": round(head["qps"], 3),

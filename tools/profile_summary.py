@@ -77,9 +77,12 @@ def main():
             "hbm_bytes_per_launch": int(mean_kib * 1024 * 2),
             "source": f"rocprofv3 --pmc FETCH_SIZE, profiles/{args.tag}_pmc_fetch_size.csv",
         }
-        with open(os.path.join(out, "scan_traffic.json"), "w") as f:
+        # the headline (p = 100 %) keeps the plain names; other pass rates get a suffix
+        sfx = "" if args.pass_percent == 100 else f"_p{args.pass_percent}"
+        rec["source"] = f"rocprofv3 --pmc FETCH_SIZE, profiles/{args.tag}_pmc_fetch_size{sfx}.csv"
+        with open(os.path.join(out, f"scan_traffic{sfx}.json"), "w") as f:
             json.dump(rec, f, indent=1)
-        with open(os.path.join(out, f"{args.tag}_pmc_fetch_size.csv"), "w") as f:
+        with open(os.path.join(out, f"{args.tag}_pmc_fetch_size{sfx}.csv"), "w") as f:
             f.write("kernel,launch,FETCH_SIZE_KiB\n")
             for i, v in enumerate(vals):
                 f.write(f"{args.kernel},{i},{v}\n")
