@@ -190,9 +190,13 @@ int32_t vs_search_mask(vs_store* s, const float* query, uint32_t dim, uint32_t k
 
 /* `n_q` queries against one shared candidate mask. out_ids / out_dist hold
  * n_q * k entries (query i at offset i * k), out_n holds n_q counts. On a
- * VS_BF16 store with k <= VS_BATCH_MAX_K this runs the batched matrix-core scan
- * (queries rounded to bf16); otherwise one scan per query. No reference
- * counterpart (the reference searches one vector per request). */
+ * VS_BF16 angular store with k <= VS_BATCH_MAX_K this runs the batched
+ * matrix-core scan (queries rounded to bf16). Otherwise groups of eight (f32 rows
+ * of up to 768 dimensions) or four queries (f32 up to 1536, bf16 up to 1536
+ * dimensions) share each pass over the rows when k <= 128, and every query's
+ * result is bit-identical to its own vs_search; anything else is one scan per
+ * query. No reference counterpart (the reference searches one vector per
+ * request). */
 int32_t vs_search_batch(vs_store* s, const float* queries, uint32_t n_q, uint32_t dim,
                         uint32_t k, const uint64_t* mask_words, uint64_t n_mask_words,
                         uint32_t* out_ids, float* out_dist, uint32_t* out_n);

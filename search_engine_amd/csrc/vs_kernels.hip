@@ -308,6 +308,208 @@ __global__ __launch_bounds__(WAVES * 64) void scan_dot_kernel(ScanArgs a) {
     scan_float_rows<VS_DOT, ELEM, NCH, U, true>(a, smem);
 }
 
+// ---- several queries per pass ---------------------------------------------------------
+//
+// The same scan with Q = 4 or 8 queries sharing every row read (vs_search_batch on stores the
+// matrix-core path does not serve: f32 rows, other metrics, k beyond its limit). A row's 12
+// FMAs per lane become 12 Q, still below what the row's HBM time allows, so a dense pass
+// costs what a single-query pass costs. Each lane carries Q partial sums; the reduction
+// transposes while it adds: at lane distance 1 the two lanes of a pair split the queries
+// between them, at distance 2 (and 4 for Q = 8) they split again, so that after log2 Q steps
+// every lane holds ONE query's partial sum, and the remaining steps up to distance 32 finish
+// all Q at once. Every level adds the same pairs as the single-query reduction does, so a
+// query's distances are bit-identical to vs_search's.
+struct MultiArgs {
+    ScanArgs s;               // query = first query; partial = first query's lists
+    uint32_t query_stride;    // floats between consecutive queries
+    uint32_t n_q;             // 1 .. Q (missing queries are not scored)
+    uint64_t partial_stride;  // keys between consecutive queries' partial lists
+};
+
+template <int XOR>
+__device__ __forceinline__ float swizzle_xor_f32(float v) {  // lane ^ XOR inside each half of the wave
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (XOR << 10) | 0x1F));
+}
+
+// Two queries' sums advance together in one packed FMA per row element (each half is the
+// IEEE operation the single-query scan performs).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int METRIC>
+__device__ __forceinline__ f32x2 pair_step(float xe, f32x2 q, f32x2 acc) {
+    const f32x2 xx = {xe, xe};
+    if (METRIC == VS_EUCLIDEAN) {
+        const f32x2 d = xx - q;
+        return __builtin_elementwise_fma(d, d, acc);
+    }
+    return __builtin_elementwise_fma(xx, q, acc);
+}
+template <int METRIC, int ELEM>
+__device__ __forceinline__ f32x2 pair_vec(u32x4 x, const f32x2* q, f32x2 acc) {
+    if (ELEM == VS_F32) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = pair_step<METRIC>(__uint_as_float(x[j]), q[j], acc);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc = pair_step<METRIC>(__uint_as_float(x[j] << 16), q[2 * j], acc);
+            acc = pair_step<METRIC>(__uint_as_float(x[j] & 0xFFFF0000u), q[2 * j + 1], acc);
+        }
+    }
+    return acc;
+}
+
+template <int METRIC, int ELEM, int NCH, int U, int Q>
+__global__ __launch_bounds__(WAVES * 64) void scan_multi_kernel(MultiArgs m) {
+    static_assert(Q == 4 || Q == 8, "four or eight queries per pass");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int EPV = Epv<ELEM>::value;
+    const ScanArgs& a = m.s;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wib = uniform_u32(threadIdx.x >> 6);
+    const uint32_t W = gridDim.x * WAVES;
+    const uint32_t w = blockIdx.x * WAVES + wib;
+    const int k = (int)a.k;
+
+    uint32_t* queue =
+        reinterpret_cast<uint32_t*>(smem + (size_t)Q * WAVES * k * 8) + (size_t)wib * QCAP;
+    WaveTopK top[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+        top[q].init(reinterpret_cast<uint64_t*>(smem) + ((size_t)q * WAVES + wib) * k, k, lane);
+
+    // Lane bits 0, 1 (, 2) choose the half, quarter (, eighth) of the queries a lane keeps in
+    // the transposing steps: it ends up speaking for query `mine`, and query q is spoken for
+    // by the lane whose low bits are q's bits in reverse order.
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+    const int mine = Q == 4 ? (b0 ? 2 : 0) + (b1 ? 1 : 0) : (b0 ? 4 : 0) + (b1 ? 2 : 0) + (b2 ? 1 : 0);
+
+    f32x2 qv[Q / 2][NCH][EPV];  // queries 2i and 2i + 1 side by side
+    float my_qn = 0.0f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const float* src = a.query + (size_t)(q < (int)m.n_q ? q : 0) * m.query_stride;
+        float qq = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) {
+                const uint32_t e = (uint32_t)(c * 64 + lane) * EPV + j;
+                const float val = e < a.dim ? src[e] : 0.0f;
+                qv[q / 2][c][j][q & 1] = val;
+                qq = __builtin_fmaf(val, val, qq);
+            }
+        }
+        const float n = sqrtf(wave_sum_f32(qq));
+        if (mine == q) my_qn = n;
+    }
+    wave_lds_fence();
+
+    auto score_rows = [&](uint32_t head, uint32_t nvalid) {
+        uint32_t slot[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t at = head + ((uint32_t)u < nvalid ? (uint32_t)u : nvalid - 1);
+            slot[u] = uniform_u32(queue[at]);
+        }
+        u32x4 x[U][NCH];
+        float pn[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const u32x4* rp = a.rows + (uint64_t)slot[u] * a.row_vecs;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const uint32_t idx = (uint32_t)(c * 64 + lane);
+                if (c < NCH - 1 || idx < a.row_vecs) {
+                    x[u][c] = load_vec<true>(rp + idx);
+                } else {
+                    x[u][c] = u32x4{0u, 0u, 0u, 0u};
+                }
+            }
+            pn[u] = METRIC == VS_ANGULAR ? a.norms[slot[u]] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float acc[Q];
+            if (ELEM == VS_BF16) {
+                // packed FMAs pay where each element also costs an unpack (3.83 -> 3.55 ms per pass
+                // of 10 M x 768 bf16); on f32 rows they were slower than plain ones (6.3 against 5.5 ms)
+#pragma unroll
+                for (int i = 0; i < Q / 2; ++i) {
+                    f32x2 s2 = {0.0f, 0.0f};
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) s2 = pair_vec<METRIC, ELEM>(x[u][c], qv[i][c], s2);
+                    acc[2 * i] = s2[0];
+                    acc[2 * i + 1] = s2[1];
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    acc[q] = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float xe = __uint_as_float(x[u][c][j]), qe = qv[q / 2][c][j][q & 1];
+                            if (METRIC == VS_EUCLIDEAN) {
+                                const float df = xe - qe;
+                                acc[q] = __builtin_fmaf(df, df, acc[q]);
+                            } else {
+                                acc[q] = __builtin_fmaf(xe, qe, acc[q]);
+                            }
+                        }
+                    }
+                }
+            }
+            // distance 1: the even lane keeps the first half of the queries, the odd one the second
+            float h[Q / 2];
+#pragma unroll
+            for (int i = 0; i < Q / 2; ++i) {
+                const float keep = b0 ? acc[i + Q / 2] : acc[i], send = b0 ? acc[i] : acc[i + Q / 2];
+                h[i] = keep + dpp_f32<0xB1, 0xF>(send);  // quad_perm [1,0,3,2]
+            }
+            // distance 2: halves again
+            float g[Q / 4];
+#pragma unroll
+            for (int i = 0; i < Q / 4; ++i) {
+                const float keep = b1 ? h[i + Q / 4] : h[i], send = b1 ? h[i] : h[i + Q / 4];
+                g[i] = keep + dpp_f32<0x4E, 0xF>(send);  // quad_perm [2,3,0,1]
+            }
+            float v;
+            if (Q == 8) {  // distance 4: the last split
+                const float keep = b2 ? g[Q / 4 - 1] : g[0], send = b2 ? g[0] : g[Q / 4 - 1];
+                v = keep + swizzle_xor_f32<4>(send);
+            } else {
+                v = g[0];
+                v += swizzle_xor_f32<4>(v);
+            }
+            v += swizzle_xor_f32<8>(v);
+            v += swizzle_xor_f32<16>(v);
+            v += __shfl_xor(v, 32, 64);
+            const float d = METRIC == VS_ANGULAR     ? angular_distance(v, pn[u], my_qn)
+                            : METRIC == VS_EUCLIDEAN ? v
+                                                     : -v;
+            const uint64_t key = make_key(f32_orderable(d), a.docid_base + slot[u]);
+            if ((uint32_t)u < nvalid) {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const int speaker = Q == 4 ? ((q & 1) << 1) | (q >> 1)
+                                               : ((q & 1) << 2) | (q & 2) | (q >> 2);
+                    const uint64_t kq = readlane_u64(key, speaker);
+                    if ((uint32_t)q < m.n_q && kq < top[q].tau) top[q].insert(kq);
+                }
+            }
+        }
+    };
+
+    scan_masked_slots<U>(a.present, a.cand, a.n_slots, w, W, lane, queue, score_rows);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        if ((uint32_t)q < m.n_q)
+            finish_block(top[q], smem + (size_t)q * WAVES * k * 8, k, wib, lane,
+                         a.partial + (uint64_t)q * m.partial_stride);
+    }
+}
+
 // ---- Hamming scan of binary-quantised rows ----------------------------------------------
 //
 // No counterpart in the reference (its only metric is Angular): distance =
@@ -794,6 +996,86 @@ hipError_t launch_scan_hamming(const SlabView& s, const void* d_query, const uin
     if (e != hipSuccess) return e;
     return launch_merge(partial, blocks, 1, blocks, k, VS_HAMMING, out_keys, out_ids, out_dist,
                         out_n, stream);
+}
+
+bool scan_multi_serves(const SlabView& s, uint32_t k) {
+    if (s.metric != VS_ANGULAR && s.metric != VS_EUCLIDEAN && s.metric != VS_DOT) return false;
+    const uint32_t nch = (s.row_vecs + 63) / 64;
+    return k >= 1 && k <= (uint32_t)WaveTopK::REG_K && nch <= (s.dtype == VS_F32 ? 6u : 3u);
+}
+
+// Queries one pass takes: eight for f32 rows of up to 768 dimensions (the query slices of
+// eight still fit the register file), four otherwise.
+uint32_t scan_multi_queries(const SlabView& s) {
+    return s.dtype == VS_F32 && (s.row_vecs + 63) / 64 <= 3 ? 8u : 4u;
+}
+
+template <int METRIC, int ELEM>
+static hipError_t launch_multi_e(const MultiArgs& m, uint32_t blocks, size_t lds, bool eight,
+                                 hipStream_t stream) {
+    const dim3 grid(blocks), block(WAVES * 64);
+    const uint32_t nch = (m.s.row_vecs + 63) / 64;
+    if (ELEM == VS_F32 && eight && nch <= 3) {
+        if (nch <= 1) hipLaunchKernelGGL((scan_multi_kernel<METRIC, VS_F32, 1, 4, 8>), grid, block, lds, stream, m);
+        else if (nch <= 2) hipLaunchKernelGGL((scan_multi_kernel<METRIC, VS_F32, 2, 4, 8>), grid, block, lds, stream, m);
+        else hipLaunchKernelGGL((scan_multi_kernel<METRIC, VS_F32, 3, 4, 8>), grid, block, lds, stream, m);
+        return hipGetLastError();
+    }
+    if (nch <= 1) hipLaunchKernelGGL((scan_multi_kernel<METRIC, ELEM, 1, 4, 4>), grid, block, lds, stream, m);
+    else if (nch <= 2) hipLaunchKernelGGL((scan_multi_kernel<METRIC, ELEM, 2, 4, 4>), grid, block, lds, stream, m);
+    else if (nch <= 3) hipLaunchKernelGGL((scan_multi_kernel<METRIC, ELEM, 3, 4, 4>), grid, block, lds, stream, m);
+    else if (ELEM == VS_F32 && nch <= 4)
+        hipLaunchKernelGGL((scan_multi_kernel<METRIC, VS_F32, 4, 2, 4>), grid, block, lds, stream, m);
+    else if (ELEM == VS_F32 && nch <= 6)
+        hipLaunchKernelGGL((scan_multi_kernel<METRIC, VS_F32, 6, 2, 4>), grid, block, lds, stream, m);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+template <int METRIC>
+static hipError_t launch_multi_m(const MultiArgs& m, int32_t dtype, uint32_t blocks, size_t lds,
+                                 bool eight, hipStream_t stream) {
+    if (dtype == VS_F32) return launch_multi_e<METRIC, VS_F32>(m, blocks, lds, eight, stream);
+    if (dtype == VS_BF16) return launch_multi_e<METRIC, VS_BF16>(m, blocks, lds, false, stream);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_scan_multi(const SlabView& s, const float* d_queries, uint32_t query_stride,
+                             uint32_t n_q, const uint64_t* cand, uint32_t k, uint64_t* partial,
+                             uint32_t* out_ids, float* out_dist, uint32_t* out_n, const ScanTuning& t,
+                             hipStream_t stream) {
+    if (!scan_multi_serves(s, k) || n_q == 0 || n_q > scan_multi_queries(s) || (s.n_slots & 63) ||
+        s.n_slots == 0 || (s.metric == VS_ANGULAR && !s.norms))
+        return hipErrorInvalidValue;
+    const bool eight = n_q > 4;  // a group of up to four runs the lighter kernel
+    const uint32_t lists = eight ? 8 : 4;
+    const uint32_t blocks = scan_grid_blocks(s, t, cand != nullptr);
+    MultiArgs m;
+    m.s.rows = reinterpret_cast<const u32x4*>(s.rows);
+    m.s.norms = s.norms;
+    m.s.present = s.present;
+    m.s.cand = cand;
+    m.s.query = d_queries;
+    m.s.partial = partial;
+    m.s.n_slots = s.n_slots;
+    m.s.row_vecs = s.row_vecs;
+    m.s.dim = s.dim;
+    m.s.docid_base = s.docid_base;
+    m.s.k = k;
+    m.s.metric = s.metric;
+    m.query_stride = query_stride;
+    m.n_q = n_q;
+    m.partial_stride = (uint64_t)blocks * k;
+    const size_t lds = (size_t)lists * WAVES * k * 8 + (size_t)WAVES * QCAP * 4;
+    hipError_t e;
+    if (s.metric == VS_ANGULAR) e = launch_multi_m<VS_ANGULAR>(m, s.dtype, blocks, lds, eight, stream);
+    else if (s.metric == VS_EUCLIDEAN) e = launch_multi_m<VS_EUCLIDEAN>(m, s.dtype, blocks, lds, eight, stream);
+    else e = launch_multi_m<VS_DOT>(m, s.dtype, blocks, lds, eight, stream);
+    if (e != hipSuccess) return e;
+    // list r of workgroup b of query q: partial[q * blocks * k + r * blocks + b]
+    return launch_merge_batch(partial, blocks, 1, blocks, n_q, (uint64_t)blocks * k, k, s.metric, nullptr,
+                              out_ids, out_dist, out_n, stream);
 }
 
 hipError_t launch_merge(const uint64_t* keys, uint32_t n_lists, uint64_t list_stride,

@@ -303,14 +303,19 @@ int32_t run_batch_and_fetch(vs_store* s, Workspace* ws, const float* h_queries, 
     return VS_OK;
 }
 
-// Several queries under one candidate mask, one scan each (f32 and binary stores, or k beyond
-// the matrix-core path): the scans of a chunk are queued back to back on the workspace's
-// stream, with ONE upload of the queries, ONE download of the results and ONE wait per chunk.
+// Several queries under one candidate mask outside the matrix-core path (f32 and binary stores,
+// other metrics, larger k): four or eight queries per pass over the rows where the multi-query scan
+// serves the store, else one scan each; the launches of a chunk are queued back to back on the
+// workspace's stream, with ONE upload of the queries, ONE download of the results and ONE wait
+// per chunk.
 int32_t run_many_and_fetch(vs_store* s, Workspace* ws, const float* h_queries, uint32_t n_q, uint32_t k,
                            const uint64_t* d_cand, uint32_t* out_ids, float* out_dist, uint32_t* out_n) {
     const vs::SlabView v = s->view();
     const vs::ScanTuning& t = s->ctx->tuning;
-    if (int32_t rc = grow(&ws->d_partial, &ws->partial_bytes, (size_t)vs::scan_partial_bytes(v, k, t)))
+    // `group` queries share every pass over the rows where the multi-query scan serves the store
+    const uint32_t group = vs::scan_multi_serves(v, k) ? vs::scan_multi_queries(v) : 1;
+    if (int32_t rc = grow(&ws->d_partial, &ws->partial_bytes,
+                          (size_t)vs::scan_partial_bytes(v, k, t) * group))
         return rc;
     const size_t chunk_q = 64;
     const bool bin = s->dtype == VS_BIN1;
@@ -338,10 +343,19 @@ int32_t run_many_and_fetch(vs_store* s, Workspace* ws, const float* h_queries, u
         float* d_dist = reinterpret_cast<float*>(d_res + chunk_q * k * 4);
         uint32_t* d_n = reinterpret_cast<uint32_t*>(d_res + chunk_q * k * 8);
         HIP_TRY(hipMemcpyAsync(ws->d_batch, hq.data(), (size_t)m * q_stride, hipMemcpyHostToDevice, ws->stream));
-        for (uint32_t i = 0; i < m; ++i)
-            if (int32_t rc = launch_scan(s, ws->d_batch + i * q_stride, d_cand, k, ws->d_partial, nullptr,
-                                         d_ids + (size_t)i * k, d_dist + (size_t)i * k, d_n + i, ws->stream))
-                return rc;
+        if (group > 1) {
+            for (uint32_t i = 0; i < m; i += group)
+                HIP_TRY(vs::launch_scan_multi(v, reinterpret_cast<const float*>(ws->d_batch + i * q_stride),
+                                              (uint32_t)(q_stride / 4), m - i < group ? m - i : group, d_cand, k,
+                                              ws->d_partial, d_ids + (size_t)i * k, d_dist + (size_t)i * k,
+                                              d_n + i, t, ws->stream));
+        } else {
+            for (uint32_t i = 0; i < m; ++i)
+                if (int32_t rc = launch_scan(s, ws->d_batch + i * q_stride, d_cand, k, ws->d_partial, nullptr,
+                                             d_ids + (size_t)i * k, d_dist + (size_t)i * k, d_n + i,
+                                             ws->stream))
+                    return rc;
+        }
         HIP_TRY(hipMemcpyAsync(hr.data(), d_res, res_bytes, hipMemcpyDeviceToHost, ws->stream));
         HIP_TRY(hipStreamSynchronize(ws->stream));
         const uint32_t* h_ids = reinterpret_cast<const uint32_t*>(hr.data());

@@ -519,3 +519,43 @@ def test_device_api_and_shard_merge(gpu_ctx):
     finally:
         for st in (whole, a, b):
             st.destroy()
+
+
+@pytest.mark.parametrize("metric_name", ["angular", "euclidean", "dot"])
+@pytest.mark.parametrize("dtype_name,dim,k", [
+    ("f32", 3, 5), ("f32", 100, 10), ("f32", 768, 10), ("f32", 768, 128), ("f32", 1000, 17),
+    ("f32", 1536, 10), ("f32", 2048, 10),     # 2048-d f32: beyond the multi-query scan, one scan per query
+    ("f32", 768, 129),                        # k beyond its register lists: likewise
+    ("bf16", 768, 64), ("bf16", 1536, 40), ("bf16", 2000, 33),
+])
+def test_queries_sharing_a_pass_equal_single_searches(gpu_ctx, metric_name, dtype_name, dim, k):
+    """vs_search_batch outside the matrix-core path shares each pass over the rows between four
+    or eight queries; every query's list must be bit-identical to its own vs_search (same ids,
+    same float bits), for batch sizes that do and do not fill the last group, with and without
+    a filter, holes in the store included."""
+    from search_engine_amd import abi
+    metric = {"angular": abi.VS_ANGULAR, "euclidean": abi.VS_EUCLIDEAN, "dot": abi.VS_DOT}[metric_name]
+    dtype = abi.VS_F32 if dtype_name == "f32" else abi.VS_BF16
+    n = 3000
+    rng = np.random.default_rng(dim * 7 + k)
+    docids = np.sort(rng.choice(n + 700, n, replace=False)).astype(np.uint32)
+    vectors = synthetic_vectors(n, dim, 300 + dim)
+    vectors[5] = 0.0          # a zero row: angular distance 0 by definition
+    vectors[11] = vectors[10]  # an exact tie
+    queries = synthetic_vectors(19, dim, 301 + dim)
+    queries[2] = vectors[10]
+    _next_index[0] += 1
+    store = gpu_ctx.create_store(_next_index[0], dim, n + 700, dtype=dtype, metric=metric)
+    try:
+        store.upload(docids, vectors)
+        store.seal()
+        for mask in (None, facet_mask(n + 700, 30)):
+            singles = [store.search(q, k, mask) for q in queries]
+            for n_q in (1, 2, 3, 4, 5, 7, 8, 9, 12, 13, 19):
+                batch = store.search_batch(queries[:n_q], k, mask)
+                assert len(batch) == n_q
+                for (ids, dist), (s_ids, s_dist) in zip(batch, singles):
+                    assert ids.tolist() == s_ids.tolist()
+                    assert dist.view(np.uint32).tolist() == s_dist.view(np.uint32).tolist()
+    finally:
+        store.destroy()
