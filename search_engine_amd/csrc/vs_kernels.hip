@@ -402,6 +402,8 @@ __global__ __launch_bounds__(WAVES * 64) void scan_multi_kernel(MultiArgs m) {
         const float n = sqrtf(wave_sum_f32(qq));
         if (mine == q) my_qn = n;
     }
+    // k-th best key of this lane's query so far; 0 (nothing is smaller) for a query the batch lacks
+    uint64_t my_tau = (uint32_t)mine < m.n_q ? KEY_NONE : 0ull;
     wave_lds_fence();
 
     auto score_rows = [&](uint32_t head, uint32_t nvalid) {
@@ -489,13 +491,18 @@ __global__ __launch_bounds__(WAVES * 64) void scan_multi_kernel(MultiArgs m) {
                             : METRIC == VS_EUCLIDEAN ? v
                                                      : -v;
             const uint64_t key = make_key(f32_orderable(d), a.docid_base + slot[u]);
-            if ((uint32_t)u < nvalid) {
+            // the first Q lanes speak for one query each and compare against its k-th best
+            // themselves; the common case (no query wants the row) costs one ballot
+            const uint64_t hits = __ballot((uint32_t)u < nvalid && lane < Q && key < my_tau);
+            if (hits) {
 #pragma unroll
                 for (int q = 0; q < Q; ++q) {
                     const int speaker = Q == 4 ? ((q & 1) << 1) | (q >> 1)
                                                : ((q & 1) << 2) | (q & 2) | (q >> 2);
-                    const uint64_t kq = readlane_u64(key, speaker);
-                    if ((uint32_t)q < m.n_q && kq < top[q].tau) top[q].insert(kq);
+                    if ((hits >> speaker) & 1) {
+                        top[q].insert(readlane_u64(key, speaker));
+                        if (mine == q) my_tau = top[q].tau;
+                    }
                 }
             }
         }
