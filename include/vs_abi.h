@@ -221,10 +221,15 @@ int32_t vs_search_device(vs_store* s, const void* d_query, uint32_t dim, uint32_
                          const uint64_t* d_mask_words, void* d_workspace, uint64_t* d_out_keys,
                          void* hip_stream);
 
-/* Batched form for VS_BF16 stores, on the matrix cores: `n_q` <= VS_BATCH_MAX_QUERIES
- * queries (f32 [n_q][dim] in device memory; rounded to bf16 on the device, so the
- * distances are those of the rounded queries) share ONE pass over the rows and one
- * candidate mask. k <= VS_BATCH_MAX_K. d_out_keys receives n_q lists of k keys.
+/* Batched form: `n_q` <= VS_BATCH_MAX_QUERIES queries (f32 [n_q][dim] in device
+ * memory) under one candidate mask; d_out_keys receives n_q lists of k keys.
+ *   - angular VS_BF16 stores, k <= VS_BATCH_MAX_K: ONE pass over the rows on the
+ *     matrix cores (queries rounded to bf16 on the device, so the distances are
+ *     those of the rounded queries);
+ *   - otherwise, f32 rows of up to 1536 dimensions or bf16 rows of up to 1536,
+ *     k <= 128: groups of eight (f32, up to 768 dimensions) or four queries share
+ *     a pass, each list bit-identical to vs_search_device's;
+ *   - anything else: VS_E_INVALID_ARG (use vs_search_device per query).
  * No reference counterpart (the reference searches one vector per request). */
 int32_t vs_search_batch_workspace_bytes(vs_store* s, uint32_t k, uint64_t* bytes);
 int32_t vs_search_batch_device(vs_store* s, const float* d_queries, uint32_t n_q, uint32_t dim,

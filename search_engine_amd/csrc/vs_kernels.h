@@ -50,13 +50,13 @@ hipError_t launch_scan_float(const SlabView& s, const float* d_query, const uint
 // one pass over the rows. Serves f32 rows of up to 1536 dimensions and bf16 rows of up to 1536,
 // k <= 128 (scan_multi_serves). Query q starts at d_queries + q * query_stride floats; `partial`
 // needs scan_multi_queries(s) times scan_partial_bytes; outputs are n_q consecutive blocks of k
-// entries and n_q counts. Results are bit-identical to n_q launch_scan_float calls.
+// entries (out_keys nullable; out_ids / out_dist / out_n nullable as a group) and n_q counts. Results are bit-identical to n_q launch_scan_float calls.
 bool scan_multi_serves(const SlabView& s, uint32_t k);
 uint32_t scan_multi_queries(const SlabView& s);
 hipError_t launch_scan_multi(const SlabView& s, const float* d_queries, uint32_t query_stride,
                              uint32_t n_q, const uint64_t* cand, uint32_t k, uint64_t* partial,
-                             uint32_t* out_ids, float* out_dist, uint32_t* out_n, const ScanTuning& t,
-                             hipStream_t stream);
+                             uint64_t* out_keys, uint32_t* out_ids, float* out_dist, uint32_t* out_n,
+                             const ScanTuning& t, hipStream_t stream);
 
 // Hamming scan of one query against a VS_BIN1 slab. `d_query` holds the packed
 // query bits, row_vecs * 16 bytes, zero padded. Outputs as launch_scan_float;

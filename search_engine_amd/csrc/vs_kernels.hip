@@ -1050,8 +1050,8 @@ static hipError_t launch_multi_m(const MultiArgs& m, int32_t dtype, uint32_t blo
 
 hipError_t launch_scan_multi(const SlabView& s, const float* d_queries, uint32_t query_stride,
                              uint32_t n_q, const uint64_t* cand, uint32_t k, uint64_t* partial,
-                             uint32_t* out_ids, float* out_dist, uint32_t* out_n, const ScanTuning& t,
-                             hipStream_t stream) {
+                             uint64_t* out_keys, uint32_t* out_ids, float* out_dist, uint32_t* out_n,
+                             const ScanTuning& t, hipStream_t stream) {
     if (!scan_multi_serves(s, k) || n_q == 0 || n_q > scan_multi_queries(s) || (s.n_slots & 63) ||
         s.n_slots == 0 || (s.metric == VS_ANGULAR && !s.norms))
         return hipErrorInvalidValue;
@@ -1081,7 +1081,7 @@ hipError_t launch_scan_multi(const SlabView& s, const float* d_queries, uint32_t
     else e = launch_multi_m<VS_DOT>(m, s.dtype, blocks, lds, eight, stream);
     if (e != hipSuccess) return e;
     // list r of workgroup b of query q: partial[q * blocks * k + r * blocks + b]
-    return launch_merge_batch(partial, blocks, 1, blocks, n_q, (uint64_t)blocks * k, k, s.metric, nullptr,
+    return launch_merge_batch(partial, blocks, 1, blocks, n_q, (uint64_t)blocks * k, k, s.metric, out_keys,
                               out_ids, out_dist, out_n, stream);
 }
 

@@ -208,6 +208,11 @@ int32_t begin_search(vs_store* s, const float* query, uint32_t dim, uint32_t k, 
     return VS_OK;
 }
 
+// Whether a batch on this store runs the matrix-core scan.
+bool on_matrix_cores(const vs_store* s, uint32_t k) {
+    return s->dtype == VS_BF16 && s->metric == VS_ANGULAR && k >= 1 && k <= VS_BATCH_MAX_K;
+}
+
 // One scan of a sealed store under its metric.
 int32_t launch_scan(vs_store* s, const void* d_query, const uint64_t* d_cand, uint32_t k,
                     uint64_t* d_partial, uint64_t* d_keys, uint32_t* d_ids, float* d_dist,
@@ -347,7 +352,7 @@ int32_t run_many_and_fetch(vs_store* s, Workspace* ws, const float* h_queries, u
             for (uint32_t i = 0; i < m; i += group)
                 HIP_TRY(vs::launch_scan_multi(v, reinterpret_cast<const float*>(ws->d_batch + i * q_stride),
                                               (uint32_t)(q_stride / 4), m - i < group ? m - i : group, d_cand, k,
-                                              ws->d_partial, d_ids + (size_t)i * k, d_dist + (size_t)i * k,
+                                              ws->d_partial, nullptr, d_ids + (size_t)i * k, d_dist + (size_t)i * k,
                                               d_n + i, t, ws->stream));
         } else {
             for (uint32_t i = 0; i < m; ++i)
@@ -932,7 +937,7 @@ extern "C" int32_t vs_search_batch(vs_store* s, const float* queries, uint32_t n
         rc = stage_dense_mask(s, ws.get(), mask_words, n_mask_words);
         d_cand = ws->d_mask;
     }
-    if (rc == VS_OK && s->dtype == VS_BF16 && s->metric == VS_ANGULAR && k <= VS_BATCH_MAX_K && n_q > 1) {
+    if (rc == VS_OK && on_matrix_cores(s, k) && n_q > 1) {
         rc = run_batch_and_fetch(s, ws.get(), queries, n_q, k, d_cand, out_ids, out_dist, out_n);
     } else if (rc == VS_OK) {
         rc = run_many_and_fetch(s, ws.get(), queries, n_q, k, d_cand, out_ids, out_dist, out_n);
@@ -969,10 +974,16 @@ extern "C" int32_t vs_search_device(vs_store* s, const void* d_query, uint32_t d
 
 extern "C" int32_t vs_search_batch_workspace_bytes(vs_store* s, uint32_t k, uint64_t* bytes) {
     if (!s || !bytes) return fail(VS_E_INVALID_ARG, "null argument");
-    if (s->dtype != VS_BF16 || s->metric != VS_ANGULAR)
-        return fail(VS_E_INVALID_ARG, "the batched path needs an angular bf16 store");
-    if (k == 0 || k > VS_BATCH_MAX_K) return fail(VS_E_INVALID_ARG, "k = %u out of range", k);
-    *bytes = vs::batch_workspace_bytes(s->view(), k);
+    const vs::SlabView v = s->view();
+    if (on_matrix_cores(s, k)) {
+        *bytes = vs::batch_workspace_bytes(v, k);
+        return VS_OK;
+    }
+    if (!vs::scan_multi_serves(v, k))
+        return fail(VS_E_INVALID_ARG,
+                    "no batched scan for this store and k = %u (angular bf16 rows with k <= %u; f32 rows "
+                    "of up to 1536 or bf16 rows of up to 1536 dimensions with k <= 128)", k, VS_BATCH_MAX_K);
+    *bytes = vs::scan_partial_bytes(v, k, s->ctx->tuning) * vs::scan_multi_queries(v);
     return VS_OK;
 }
 
@@ -982,19 +993,30 @@ extern "C" int32_t vs_search_batch_device(vs_store* s, const float* d_queries, u
     if (int32_t rc = check_store(s)) return rc;
     if (!d_queries || !d_workspace || !d_out_keys) return fail(VS_E_INVALID_ARG, "null device buffer");
     if (!s->sealed.load()) return fail(VS_E_NOT_SEALED, "store %u was never sealed", s->index);
-    if (s->dtype != VS_BF16 || s->metric != VS_ANGULAR)
-        return fail(VS_E_INVALID_ARG, "the batched path needs an angular bf16 store");
     if (dim != s->dim) {
         g_dim_expected = s->dim;
         g_dim_received = dim;
         return fail(VS_E_DIM_MISMATCH, "invalid vector dimensions: expected %u, received %u", s->dim,
                     dim);
     }
-    if (k == 0 || k > VS_BATCH_MAX_K || n_q == 0 || n_q > VS_BATCH_MAX_QUERIES)
-        return fail(VS_E_INVALID_ARG, "k = %u or n_q = %u out of range", k, n_q);
-    HIP_TRY(vs::launch_scan_batch_bf16(s->view(), d_queries, n_q, d_mask_words, k, d_workspace,
-                                       d_out_keys, nullptr, nullptr, nullptr,
-                                       static_cast<hipStream_t>(hip_stream)));
+    if (n_q == 0 || n_q > VS_BATCH_MAX_QUERIES)
+        return fail(VS_E_INVALID_ARG, "n_q = %u out of range", n_q);
+    const vs::SlabView v = s->view();
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    if (on_matrix_cores(s, k)) {
+        HIP_TRY(vs::launch_scan_batch_bf16(v, d_queries, n_q, d_mask_words, k, d_workspace, d_out_keys,
+                                           nullptr, nullptr, nullptr, stream));
+        return VS_OK;
+    }
+    if (!vs::scan_multi_serves(v, k))
+        return fail(VS_E_INVALID_ARG, "no batched scan for this store and k = %u", k);
+    // groups of four or eight queries share a pass; the groups run one after another on the stream
+    const uint32_t group = vs::scan_multi_queries(v);
+    for (uint32_t i = 0; i < n_q; i += group)
+        HIP_TRY(vs::launch_scan_multi(v, d_queries + (size_t)i * dim, dim, n_q - i < group ? n_q - i : group,
+                                      d_mask_words, k, static_cast<uint64_t*>(d_workspace),
+                                      d_out_keys + (size_t)i * k, nullptr, nullptr, nullptr, s->ctx->tuning,
+                                      stream));
     return VS_OK;
 }
 

@@ -154,11 +154,26 @@ def test_batch_and_device_entry_points(gpu_ctx, m):
         batch = store.search_batch(queries, k, mask)
         for (a, b), (c, d) in zip(singles, batch):
             assert a.tolist() == c.tolist() and b.tolist() == d.tolist()
-        with pytest.raises(abi.VsError):
-            store.batch_workspace_bytes(k)
-        # two shards, device buffers, one merge
+        # the device-buffer batch entry point: groups of four queries per pass, keys as vs_search_device's
         dev = torch.device("cuda:0")
         stream = torch.cuda.current_stream().cuda_stream
+        d_all = torch.from_numpy(queries).to(dev)
+        d_full_mask = torch.from_numpy(mask.view(np.int64).copy()).to(dev)
+        bws = torch.empty(store.batch_workspace_bytes(k), dtype=torch.uint8, device=dev)
+        bkeys = torch.empty(len(queries) * k, dtype=torch.int64, device=dev)
+        store.search_batch_device(d_all.data_ptr(), len(queries), dim, k, d_full_mask.data_ptr(),
+                                  bws.data_ptr(), bkeys.data_ptr(), stream)
+        sws = torch.empty(store.workspace_bytes(k), dtype=torch.uint8, device=dev)
+        skeys = torch.empty(k, dtype=torch.int64, device=dev)
+        for j in range(len(queries)):
+            store.search_device(d_all[j].data_ptr(), dim, k, d_full_mask.data_ptr(), sws.data_ptr(),
+                                skeys.data_ptr(), stream)
+            torch.cuda.synchronize()
+            assert bkeys[j * k:(j + 1) * k].tolist() == skeys.tolist()
+            assert (skeys.cpu().numpy().view(np.uint64) & 0xFFFFFFFF).tolist() == singles[j][0].tolist()
+        with pytest.raises(abi.VsError):
+            store.batch_workspace_bytes(129)  # beyond the register lists of the shared-pass scan
+        # two shards, device buffers, one merge
         keys = torch.empty(2 * k, dtype=torch.int64, device=dev)
         dq = torch.from_numpy(queries[0]).to(dev)
         keep = []
