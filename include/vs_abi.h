@@ -191,11 +191,14 @@ int32_t vs_search_mask(vs_store* s, const float* query, uint32_t dim, uint32_t k
 /* `n_q` queries against one shared candidate mask. out_ids / out_dist hold
  * n_q * k entries (query i at offset i * k), out_n holds n_q counts. On a
  * VS_BF16 angular store with k <= VS_BATCH_MAX_K this runs the batched
- * matrix-core scan (queries rounded to bf16). Otherwise groups of eight (f32 rows
- * of up to 768 dimensions) or four queries (f32 up to 1536, bf16 up to 1536
- * dimensions) share each pass over the rows when k <= 128, and every query's
- * result is bit-identical to its own vs_search; anything else is one scan per
- * query. No reference counterpart (the reference searches one vector per
+ * matrix-core scan (queries rounded to bf16). On an f32 angular or dot-product
+ * store of up to 768 dimensions with k <= 32, batches of 17 or more queries go
+ * 32 at a time through the f32 matrix cores (exact f32 products, another
+ * summation order: distances equal vs_search's up to rounding). Otherwise groups
+ * of eight (f32 rows of up to 768 dimensions) or four queries (f32 up to 1536,
+ * bf16 up to 1536 dimensions) share each pass over the rows when k <= 128, and
+ * every query's result is bit-identical to its own vs_search; anything else is
+ * one scan per query. No reference counterpart (the reference searches one vector per
  * request). */
 int32_t vs_search_batch(vs_store* s, const float* queries, uint32_t n_q, uint32_t dim,
                         uint32_t k, const uint64_t* mask_words, uint64_t n_mask_words,
@@ -226,6 +229,9 @@ int32_t vs_search_device(vs_store* s, const void* d_query, uint32_t dim, uint32_
  *   - angular VS_BF16 stores, k <= VS_BATCH_MAX_K: ONE pass over the rows on the
  *     matrix cores (queries rounded to bf16 on the device, so the distances are
  *     those of the rounded queries);
+ *   - f32 angular / dot-product stores of up to 768 dimensions, k <= 32, 17 or
+ *     more queries: 32 per pass on the f32 matrix cores (distances equal
+ *     vs_search_device's up to rounding);
  *   - otherwise, f32 rows of up to 1536 dimensions or bf16 rows of up to 1536,
  *     k <= 128: groups of eight (f32, up to 768 dimensions) or four queries share
  *     a pass, each list bit-identical to vs_search_device's;

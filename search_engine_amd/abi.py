@@ -17,7 +17,8 @@ VS_ANGULAR, VS_HAMMING, VS_EUCLIDEAN, VS_DOT = 0, 1, 2, 3
 VS_KEY_NONE = 0xFFFFFFFFFFFFFFFF
 VS_MAX_K = 1024
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvs_amd.so")
+# VS_AMD_LIB names another build of the same library (measurement variants of the tools)
+LIB_PATH = os.environ.get("VS_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvs_amd.so")
 
 _vp = ctypes.c_void_p
 _u8p = ctypes.POINTER(ctypes.c_uint8)

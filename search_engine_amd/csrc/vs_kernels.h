@@ -58,6 +58,17 @@ hipError_t launch_scan_multi(const SlabView& s, const float* d_queries, uint32_t
                              uint64_t* out_keys, uint32_t* out_ids, float* out_dist, uint32_t* out_n,
                              const ScanTuning& t, hipStream_t stream);
 
+// Up to 32 queries in one pass over an f32 slab on the f32 matrix cores (angular or dot product,
+// rows of up to 768 dimensions, k <= 32: scan_mq32_serves). `partial` needs
+// scan_mq32_partial_bytes. Arguments and outputs as launch_scan_multi; distances agree with
+// launch_scan_float within rounding (a different summation order), not bit for bit.
+bool scan_mq32_serves(const SlabView& s, uint32_t k);
+uint64_t scan_mq32_partial_bytes(const SlabView& s, uint32_t k);
+hipError_t launch_scan_mq32(const SlabView& s, const float* d_queries, uint32_t query_stride,
+                            uint32_t n_q, const uint64_t* cand, uint32_t k, uint64_t* partial,
+                            uint64_t* out_keys, uint32_t* out_ids, float* out_dist, uint32_t* out_n,
+                            hipStream_t stream);
+
 // Hamming scan of one query against a VS_BIN1 slab. `d_query` holds the packed
 // query bits, row_vecs * 16 bytes, zero padded. Outputs as launch_scan_float;
 // a key's distance field is the integer Hamming distance.

@@ -517,6 +517,247 @@ __global__ __launch_bounds__(WAVES * 64) void scan_multi_kernel(MultiArgs m) {
     }
 }
 
+// ---- 32 queries per pass on the f32 matrix cores ----------------------------------------
+//
+// v_mfma_f32_32x32x2_f32 multiplies exact f32 operands and accumulates like a chain of fmaf,
+// at 1/16 of the bf16 rate: 2 * 32 * dim flop per row are about what a CU can do in the row's
+// HBM time, so THIRTY-TWO queries ride on one pass over an f32 slab (measured on 10 M x 768:
+// 7.3 ms per pass against 4.4 ms for a single-query pass; a build without the row loads takes
+// 5.4 ms, i.e. the matrix cores at the clock they hold under this load are the floor).
+// One wave = one 32-row x 32-query tile:
+//   * the 32 queries sit in LDS for the whole kernel (row-major, 4 floats of padding);
+//   * rows come from the candidate queue, so a filter skips rows exactly as in the
+//     single-query scan. A chunk = 32 floats of each of the 32 rows: four loads in which
+//     eight lanes cover one row's 128-byte line, three chunks requested ahead;
+//   * a chunk goes through a per-wave LDS staging tile (stride 36 floats) to turn "lane =
+//     piece of a row" into the operand layout "lane = row (mod 32), k = lane / 32"; lanes of
+//     the upper half read the floats 4 further, which merely permutes the order in which a
+//     row's products are added;
+//   * the accumulators give a lane 16 rows of ONE query (lane & 31). It evaluates the
+//     distance, compares with that query's k-th best (LDS, per wave) and inserts survivors
+//     into the query's sorted list in LDS itself -- the two halves of the wave take turns,
+//     they share queries.
+// Sums are k-ordered fmaf chains, not the lane tree of the scans above: distances agree with
+// vs_search within rounding, not bit for bit. Angular and dot product only (a squared
+// distance assembled from norms and a product would cancel for near neighbours).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int MQ = 32;                   // queries per pass
+constexpr uint32_t MQ_MAX_K = 32;        // per-wave lists of every query live in LDS
+constexpr uint32_t MQ_MAX_VECS = 192;    // 768 f32 per row: the query block must fit LDS
+constexpr int MQ_STAGE_STRIDE = 36;      // floats per staged row (32 + 4 against bank conflicts)
+constexpr int MQ_DEPTH = 8;              // chunks requested ahead (even: the fragment sets alternate): 32 KiB per wave
+
+struct Mq32Args {
+    ScanArgs s;               // query = first query; partial = first query's lists
+    uint32_t query_stride;    // floats between consecutive queries
+    uint32_t n_q;             // 1 .. 32
+    uint64_t partial_stride;  // keys between consecutive queries' partial lists
+};
+
+__host__ __device__ inline uint32_t mq32_chunks(uint32_t row_vecs) { return (row_vecs + 7) / 8; }
+__host__ __device__ inline uint32_t mq32_qstride(uint32_t row_vecs) { return mq32_chunks(row_vecs) * 32 + 4; }
+static size_t mq32_lds_bytes(uint32_t row_vecs, uint32_t k) {
+    return (size_t)MQ * mq32_qstride(row_vecs) * 4          // queries
+           + (size_t)WAVES * 32 * MQ_STAGE_STRIDE * 4       // staging tiles
+           + (size_t)WAVES * MQ * k * 8                     // lists
+           + (size_t)WAVES * MQ * 8                         // k-th best per query
+           + (size_t)WAVES * 32 * 8                         // slot and norm of the tile's rows
+           + (size_t)WAVES * QCAP * 4                       // candidate queues
+           + (size_t)MQ * 4;                                // query norms
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(WAVES * 64) void scan_mq32_kernel(Mq32Args m) {
+    static_assert(METRIC == VS_ANGULAR || METRIC == VS_DOT, "angular or dot product");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const ScanArgs& a = m.s;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wib = uniform_u32(threadIdx.x >> 6);
+    const uint32_t W = gridDim.x * WAVES;
+    const uint32_t w = blockIdx.x * WAVES + wib;
+    const int k = (int)a.k;
+    const uint32_t n_chunks = mq32_chunks(a.row_vecs);
+    const uint32_t qstride = mq32_qstride(a.row_vecs);
+
+    float* qmat = reinterpret_cast<float*>(smem);
+    float* stage = qmat + (size_t)MQ * qstride + (size_t)wib * 32 * MQ_STAGE_STRIDE;
+    unsigned char* after_stage =
+        reinterpret_cast<unsigned char*>(qmat + (size_t)MQ * qstride + (size_t)WAVES * 32 * MQ_STAGE_STRIDE);
+    uint64_t* lists = reinterpret_cast<uint64_t*>(after_stage) + (size_t)wib * MQ * k;
+    uint64_t* tau = reinterpret_cast<uint64_t*>(after_stage) + (size_t)WAVES * MQ * k + (size_t)wib * MQ;
+    unsigned char* after_tau = after_stage + (size_t)WAVES * MQ * k * 8 + (size_t)WAVES * MQ * 8;
+    uint32_t* row_slot = reinterpret_cast<uint32_t*>(after_tau) + (size_t)wib * 64;
+    float* row_norm = reinterpret_cast<float*>(row_slot + 32);
+    uint32_t* queue = reinterpret_cast<uint32_t*>(after_tau + (size_t)WAVES * 32 * 8) + (size_t)wib * QCAP;
+    float* qnorm = reinterpret_cast<float*>(after_tau + (size_t)WAVES * 32 * 8 + (size_t)WAVES * QCAP * 4);
+
+    // the query block, zero padded to whole chunks; missing queries are zero
+    for (uint32_t i = threadIdx.x; i < (uint32_t)MQ * qstride; i += blockDim.x) {
+        const uint32_t q = i / qstride, e = i - q * qstride;
+        qmat[i] = (q < m.n_q && e < a.dim) ? a.query[(size_t)q * m.query_stride + e] : 0.0f;
+    }
+    __syncthreads();
+    // norms of the queries, summed in the order the single-query scan uses
+    for (uint32_t q = wib; q < (uint32_t)MQ; q += WAVES) {
+        float qq = 0.0f;
+        for (uint32_t c = 0; c * 64 < a.row_vecs; ++c) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t e = (c * 64 + (uint32_t)lane) * 4 + j;
+                const float v = e < a.dim ? qmat[q * qstride + e] : 0.0f;
+                qq = __builtin_fmaf(v, v, qq);
+            }
+        }
+        const float n = sqrtf(wave_sum_f32(qq));
+        if (lane == 0) qnorm[q] = n;
+    }
+    for (int i = lane; i < MQ * k; i += 64) lists[i] = KEY_NONE;
+    if (lane < MQ) tau[lane] = (uint32_t)lane < m.n_q ? KEY_NONE : 0ull;  // 0: nothing is smaller
+    __syncthreads();
+    const uint32_t col = (uint32_t)lane & 31, half = (uint32_t)lane >> 5;
+    const float my_qn = qnorm[col];
+    uint64_t* my_list = lists + (size_t)col * k;
+
+    auto score_rows = [&](uint32_t head, uint32_t nvalid) {
+        if (lane < 32) {
+            const uint32_t slot = queue[head + ((uint32_t)lane < nvalid ? (uint32_t)lane : nvalid - 1)];
+            row_slot[lane] = slot;
+            row_norm[lane] = METRIC == VS_ANGULAR ? a.norms[slot] : 0.0f;
+        }
+        wave_lds_fence();
+        const uint32_t piece = (uint32_t)lane & 7, r0 = (uint32_t)lane >> 3;
+        const u32x4* base[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            base[i] = a.rows + (uint64_t)row_slot[r0 + 8 * i] * a.row_vecs + piece;
+        // Nothing in the steady state below is conditional: a load that is issued only on some
+        // paths makes the compiler wait for ALL outstanding loads at the next use, which would
+        // undo the prefetch. Chunks past the end are clamped to the last one (a repeated read
+        // that is never used), pieces past the end of a row read the row's last vector and are
+        // zeroed on their way into the staging tile.
+        const uint32_t last_chunk = n_chunks - 1;
+        auto request = [&](uint32_t c, u32x4 (&dst)[4]) {
+            const uint32_t cc = c < last_chunk ? c : last_chunk;
+            uint32_t v = cc * 8 + piece;
+            v = v < a.row_vecs ? v : a.row_vecs - 1;
+            v -= piece;  // base[] already points at this lane's piece
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[i] = load_vec<true>(base[i] + (int32_t)v);
+        };
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+        u32x4 buf[MQ_DEPTH][4];
+#pragma unroll
+        for (int d = 0; d < MQ_DEPTH; ++d) request((uint32_t)d, buf[d]);
+        const float* arow = stage + col * MQ_STAGE_STRIDE + 4 * half;
+        const float* brow = qmat + (size_t)col * qstride + 4 * half;
+        auto to_stage = [&](uint32_t c, const u32x4 (&src)[4]) {
+            const bool in_row = c * 8 + piece < a.row_vecs;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<u32x4*>(stage + (r0 + 8 * i) * MQ_STAGE_STRIDE + piece * 4) =
+                    in_row ? src[i] : u32x4{0u, 0u, 0u, 0u};
+        };
+        auto fragments = [&](uint32_t c, f32x4 (&fa)[4], f32x4 (&fb)[4]) {
+#pragma unroll
+            for (int mm = 0; mm < 4; ++mm) {
+                fa[mm] = *reinterpret_cast<const f32x4*>(arow + 8 * mm);
+                fb[mm] = *reinterpret_cast<const f32x4*>(brow + c * 32 + 8 * mm);
+            }
+        };
+        // Software pipeline, one wave per SIMD: while the 16 MFMAs of chunk c run, chunk c + 1 is
+        // already on its way through the staging tile into the other fragment set (LDS executes
+        // a wave's operations in order, so its reads of chunk c are done before the overwrite),
+        // and the rows of chunk c + MQ_DEPTH are on their way from HBM. One step past the last
+        // chunk stages and reads a repeated chunk that no MFMA consumes (the fragment read of
+        // the query block then runs at most 32 floats past a query's row: still inside LDS).
+        f32x4 fa[2][4], fb[2][4];
+        to_stage(0, buf[0]);
+        request((uint32_t)MQ_DEPTH, buf[0]);
+        wave_lds_fence();
+        fragments(0, fa[0], fb[0]);
+        auto step = [&](uint32_t c, const int d) {
+            wave_lds_fence();
+            to_stage(c + 1, buf[(d + 1) % MQ_DEPTH]);
+            request(c + 1 + MQ_DEPTH, buf[(d + 1) % MQ_DEPTH]);
+            wave_lds_fence();
+            fragments(c + 1, fa[(d + 1) & 1], fb[(d + 1) & 1]);
+#pragma unroll
+            for (int mm = 0; mm < 4; ++mm) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[d & 1][mm][t], fb[d & 1][mm][t], acc, 0, 0, 0);
+            }
+        };
+        uint32_t c0 = 0;
+        for (; c0 + MQ_DEPTH <= n_chunks; c0 += MQ_DEPTH) {
+#pragma unroll
+            for (int d = 0; d < MQ_DEPTH; ++d) step(c0 + (uint32_t)d, d);
+        }
+#pragma unroll
+        for (int d = 0; d < MQ_DEPTH; ++d)  // fewer than MQ_DEPTH chunks are left
+            if (c0 + (uint32_t)d < n_chunks) step(c0 + (uint32_t)d, d);
+        wave_lds_fence();
+        // lane: query `col`, rows (e & 3) + 8 (e >> 2) + 4 half
+        uint64_t key[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const uint32_t r = (uint32_t)((e & 3) + 8 * (e >> 2)) + 4 * half;
+            const float d = METRIC == VS_ANGULAR ? angular_distance(acc[e], row_norm[r], my_qn) : -acc[e];
+            key[e] = r < nvalid ? make_key(f32_orderable(d), a.docid_base + row_slot[r]) : KEY_NONE;
+        }
+#pragma unroll 1
+        for (uint32_t turn = 0; turn < 2; ++turn) {
+            if (half == turn) {
+                uint64_t t = tau[col];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    if (key[e] < t) {
+                        int pos = k - 1;
+                        while (pos > 0 && my_list[pos - 1] > key[e]) {
+                            my_list[pos] = my_list[pos - 1];
+                            --pos;
+                        }
+                        my_list[pos] = key[e];
+                        t = my_list[k - 1];
+                    }
+                }
+                tau[col] = t;
+            }
+            wave_lds_fence();
+        }
+    };
+
+    scan_masked_slots<32>(a.present, a.cand, a.n_slots, w, W, lane, queue, score_rows);
+    __syncthreads();
+    // thread q of the workgroup merges the four waves' lists of query q
+    if (threadIdx.x < m.n_q) {
+        const uint64_t* all = reinterpret_cast<const uint64_t*>(after_stage);
+        uint32_t at[WAVES];
+#pragma unroll
+        for (int v = 0; v < WAVES; ++v) at[v] = 0;
+        uint64_t* out = a.partial + (uint64_t)threadIdx.x * m.partial_stride;
+        for (int r = 0; r < k; ++r) {
+            uint64_t best = KEY_NONE;
+            int from = 0;
+#pragma unroll
+            for (int v = 0; v < WAVES; ++v) {
+                const uint64_t cand =
+                    at[v] < (uint32_t)k ? all[((size_t)v * MQ + threadIdx.x) * k + at[v]] : KEY_NONE;
+                if (cand < best) {
+                    best = cand;
+                    from = v;
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < WAVES; ++v)
+                if (v == from && best != KEY_NONE) ++at[v];
+            out[(uint64_t)r * gridDim.x + blockIdx.x] = best;
+        }
+    }
+}
+
 // ---- Hamming scan of binary-quantised rows ----------------------------------------------
 //
 // No counterpart in the reference (its only metric is Angular): distance =
@@ -1081,6 +1322,54 @@ hipError_t launch_scan_multi(const SlabView& s, const float* d_queries, uint32_t
     else e = launch_multi_m<VS_DOT>(m, s.dtype, blocks, lds, eight, stream);
     if (e != hipSuccess) return e;
     // list r of workgroup b of query q: partial[q * blocks * k + r * blocks + b]
+    return launch_merge_batch(partial, blocks, 1, blocks, n_q, (uint64_t)blocks * k, k, s.metric, out_keys,
+                              out_ids, out_dist, out_n, stream);
+}
+
+bool scan_mq32_serves(const SlabView& s, uint32_t k) {
+    return s.dtype == VS_F32 && (s.metric == VS_ANGULAR || s.metric == VS_DOT) && k >= 1 &&
+           k <= MQ_MAX_K && s.row_vecs <= MQ_MAX_VECS;
+}
+uint32_t scan_mq32_blocks(const SlabView& s) {
+    const uint64_t want = (s.n_slots + 1023) / 1024;
+    return (uint32_t)(want < 1 ? 1 : want > NUM_CUS ? NUM_CUS : want);  // the query block fills a CU's LDS
+}
+uint64_t scan_mq32_partial_bytes(const SlabView& s, uint32_t k) {
+    return (uint64_t)MQ * scan_mq32_blocks(s) * k * sizeof(uint64_t);
+}
+
+hipError_t launch_scan_mq32(const SlabView& s, const float* d_queries, uint32_t query_stride,
+                            uint32_t n_q, const uint64_t* cand, uint32_t k, uint64_t* partial,
+                            uint64_t* out_keys, uint32_t* out_ids, float* out_dist, uint32_t* out_n,
+                            hipStream_t stream) {
+    if (!scan_mq32_serves(s, k) || n_q == 0 || n_q > (uint32_t)MQ || (s.n_slots & 63) || s.n_slots == 0 ||
+        (s.metric == VS_ANGULAR && !s.norms))
+        return hipErrorInvalidValue;
+    const uint32_t blocks = scan_mq32_blocks(s);
+    Mq32Args m;
+    m.s.rows = reinterpret_cast<const u32x4*>(s.rows);
+    m.s.norms = s.norms;
+    m.s.present = s.present;
+    m.s.cand = cand;
+    m.s.query = d_queries;
+    m.s.partial = partial;
+    m.s.n_slots = s.n_slots;
+    m.s.row_vecs = s.row_vecs;
+    m.s.dim = s.dim;
+    m.s.docid_base = s.docid_base;
+    m.s.k = k;
+    m.s.metric = s.metric;
+    m.query_stride = query_stride;
+    m.n_q = n_q;
+    m.partial_stride = (uint64_t)blocks * k;
+    const size_t lds = mq32_lds_bytes(s.row_vecs, k);
+    void (*kernel)(Mq32Args) = s.metric == VS_ANGULAR ? scan_mq32_kernel<VS_ANGULAR> : scan_mq32_kernel<VS_DOT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(WAVES * 64), lds, stream, m);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
     return launch_merge_batch(partial, blocks, 1, blocks, n_q, (uint64_t)blocks * k, k, s.metric, out_keys,
                               out_ids, out_dist, out_n, stream);
 }

@@ -213,6 +213,44 @@ bool on_matrix_cores(const vs_store* s, uint32_t k) {
     return s->dtype == VS_BF16 && s->metric == VS_ANGULAR && k >= 1 && k <= VS_BATCH_MAX_K;
 }
 
+// Batches outside the bf16 matrix-core path. Queues the scans of `n` queries (device memory,
+// `stride` floats apart) under one candidate mask: 32 at a time on the f32 matrix cores while
+// more than 16 are left and that scan serves the store, then 8 or 4 at a time sharing plain
+// passes. Outputs per query: k keys at keys + i * k (nullable) and/or ids, distances, counts.
+// The caller has checked shared_pass_serves().
+bool shared_pass_serves(const vs::SlabView& v, uint32_t k) { return vs::scan_multi_serves(v, k); }
+constexpr uint32_t MQ32_MIN_QUERIES = 17;
+uint64_t shared_pass_partial_bytes(const vs::SlabView& v, uint32_t k, const vs::ScanTuning& t) {
+    const uint64_t a = vs::scan_partial_bytes(v, k, t) * vs::scan_multi_queries(v);
+    const uint64_t b = vs::scan_mq32_serves(v, k) ? vs::scan_mq32_partial_bytes(v, k) : 0;
+    return a > b ? a : b;
+}
+int32_t queue_shared_passes(const vs::SlabView& v, const vs::ScanTuning& t, const float* d_q, uint32_t stride,
+                            uint32_t n, const uint64_t* d_cand, uint32_t k, uint64_t* d_partial,
+                            uint64_t* keys, uint32_t* ids, float* dist, uint32_t* counts,
+                            hipStream_t stream) {
+    const uint32_t small = vs::scan_multi_queries(v);
+    const bool mfma = vs::scan_mq32_serves(v, k);
+    for (uint32_t i = 0; i < n;) {
+        const uint32_t left = n - i;
+        const float* q = d_q + (size_t)i * stride;
+        uint64_t* ko = keys ? keys + (size_t)i * k : nullptr;
+        uint32_t* io = ids ? ids + (size_t)i * k : nullptr;
+        float* fo = ids ? dist + (size_t)i * k : nullptr;
+        uint32_t* no = ids ? counts + i : nullptr;
+        if (mfma && left >= MQ32_MIN_QUERIES) {
+            const uint32_t m = left < 32 ? left : 32;
+            HIP_TRY(vs::launch_scan_mq32(v, q, stride, m, d_cand, k, d_partial, ko, io, fo, no, stream));
+            i += m;
+        } else {
+            const uint32_t m = left < small ? left : small;
+            HIP_TRY(vs::launch_scan_multi(v, q, stride, m, d_cand, k, d_partial, ko, io, fo, no, t, stream));
+            i += m;
+        }
+    }
+    return VS_OK;
+}
+
 // One scan of a sealed store under its metric.
 int32_t launch_scan(vs_store* s, const void* d_query, const uint64_t* d_cand, uint32_t k,
                     uint64_t* d_partial, uint64_t* d_keys, uint32_t* d_ids, float* d_dist,
@@ -309,18 +347,19 @@ int32_t run_batch_and_fetch(vs_store* s, Workspace* ws, const float* h_queries, 
 }
 
 // Several queries under one candidate mask outside the matrix-core path (f32 and binary stores,
-// other metrics, larger k): four or eight queries per pass over the rows where the multi-query scan
-// serves the store, else one scan each; the launches of a chunk are queued back to back on the
+// other metrics, larger k): 32, eight or four queries per pass over the rows where a multi-query
+// scan serves the store, else one scan each; the launches of a chunk are queued back to back on the
 // workspace's stream, with ONE upload of the queries, ONE download of the results and ONE wait
 // per chunk.
 int32_t run_many_and_fetch(vs_store* s, Workspace* ws, const float* h_queries, uint32_t n_q, uint32_t k,
                            const uint64_t* d_cand, uint32_t* out_ids, float* out_dist, uint32_t* out_n) {
     const vs::SlabView v = s->view();
     const vs::ScanTuning& t = s->ctx->tuning;
-    // `group` queries share every pass over the rows where the multi-query scan serves the store
-    const uint32_t group = vs::scan_multi_serves(v, k) ? vs::scan_multi_queries(v) : 1;
+    // several queries share every pass over the rows where one of the multi-query scans serves the store
+    const bool shared = shared_pass_serves(v, k);
     if (int32_t rc = grow(&ws->d_partial, &ws->partial_bytes,
-                          (size_t)vs::scan_partial_bytes(v, k, t) * group))
+                          shared ? (size_t)shared_pass_partial_bytes(v, k, t)
+                                 : (size_t)vs::scan_partial_bytes(v, k, t)))
         return rc;
     const size_t chunk_q = 64;
     const bool bin = s->dtype == VS_BIN1;
@@ -348,12 +387,11 @@ int32_t run_many_and_fetch(vs_store* s, Workspace* ws, const float* h_queries, u
         float* d_dist = reinterpret_cast<float*>(d_res + chunk_q * k * 4);
         uint32_t* d_n = reinterpret_cast<uint32_t*>(d_res + chunk_q * k * 8);
         HIP_TRY(hipMemcpyAsync(ws->d_batch, hq.data(), (size_t)m * q_stride, hipMemcpyHostToDevice, ws->stream));
-        if (group > 1) {
-            for (uint32_t i = 0; i < m; i += group)
-                HIP_TRY(vs::launch_scan_multi(v, reinterpret_cast<const float*>(ws->d_batch + i * q_stride),
-                                              (uint32_t)(q_stride / 4), m - i < group ? m - i : group, d_cand, k,
-                                              ws->d_partial, nullptr, d_ids + (size_t)i * k, d_dist + (size_t)i * k,
-                                              d_n + i, t, ws->stream));
+        if (shared) {
+            if (int32_t rc = queue_shared_passes(v, t, reinterpret_cast<const float*>(ws->d_batch),
+                                                 (uint32_t)(q_stride / 4), m, d_cand, k, ws->d_partial, nullptr,
+                                                 d_ids, d_dist, d_n, ws->stream))
+                return rc;
         } else {
             for (uint32_t i = 0; i < m; ++i)
                 if (int32_t rc = launch_scan(s, ws->d_batch + i * q_stride, d_cand, k, ws->d_partial, nullptr,
@@ -979,11 +1017,11 @@ extern "C" int32_t vs_search_batch_workspace_bytes(vs_store* s, uint32_t k, uint
         *bytes = vs::batch_workspace_bytes(v, k);
         return VS_OK;
     }
-    if (!vs::scan_multi_serves(v, k))
+    if (!shared_pass_serves(v, k))
         return fail(VS_E_INVALID_ARG,
                     "no batched scan for this store and k = %u (angular bf16 rows with k <= %u; f32 rows "
                     "of up to 1536 or bf16 rows of up to 1536 dimensions with k <= 128)", k, VS_BATCH_MAX_K);
-    *bytes = vs::scan_partial_bytes(v, k, s->ctx->tuning) * vs::scan_multi_queries(v);
+    *bytes = shared_pass_partial_bytes(v, k, s->ctx->tuning);
     return VS_OK;
 }
 
@@ -1008,16 +1046,11 @@ extern "C" int32_t vs_search_batch_device(vs_store* s, const float* d_queries, u
                                            nullptr, nullptr, nullptr, stream));
         return VS_OK;
     }
-    if (!vs::scan_multi_serves(v, k))
+    if (!shared_pass_serves(v, k))
         return fail(VS_E_INVALID_ARG, "no batched scan for this store and k = %u", k);
-    // groups of four or eight queries share a pass; the groups run one after another on the stream
-    const uint32_t group = vs::scan_multi_queries(v);
-    for (uint32_t i = 0; i < n_q; i += group)
-        HIP_TRY(vs::launch_scan_multi(v, d_queries + (size_t)i * dim, dim, n_q - i < group ? n_q - i : group,
-                                      d_mask_words, k, static_cast<uint64_t*>(d_workspace),
-                                      d_out_keys + (size_t)i * k, nullptr, nullptr, nullptr, s->ctx->tuning,
-                                      stream));
-    return VS_OK;
+    return queue_shared_passes(v, s->ctx->tuning, d_queries, dim, n_q, d_mask_words, k,
+                               static_cast<uint64_t*>(d_workspace), d_out_keys, nullptr, nullptr, nullptr,
+                               stream);
 }
 
 extern "C" int32_t vs_merge_topk_device(vs_ctx* ctx, const uint64_t* d_keys, uint32_t n_lists,
