@@ -342,13 +342,20 @@ def batched_bench(args, ctx, store, dev, stream, queries, first, n_slots, n_loca
                              "mfma_frac_of_2500_per_gpu": round(flop / (ms * 1e-3) / 1e12 / (2500.0 * world), 4)},
             }), flush=True)
         else:
-            # groups of 8 (f32, dim <= 768) or 4 queries share each pass over the rows
-            group = 8 if args.dtype == "f32" and dim <= 768 else 4
-            passes = -(-b // group)
+            # 32 queries per pass on the f32 matrix cores (17 or more f32 queries, dim <= 768, k <= 32);
+            # else groups of 8 (f32, dim <= 768) or 4 queries share each pass over the rows
+            if args.dtype == "f32" and dim <= 768 and k <= 32 and b >= 17:
+                group = 32
+                passes = b // 32 + (1 if b % 32 >= 17 else -(-(b % 32) // 8))
+            else:
+                group = 8 if args.dtype == "f32" and dim <= 768 else 4
+                passes = -(-b // group)
             row_bytes = dim * (4 if args.dtype == "f32" else 2) + 4
-            gbps = passes * args.docs * row_bytes / (ms * 1e-3) / 1e9  # p = 100 % only
+            lut = torch.tensor([bin(v).count("1") for v in range(256)], dtype=torch.int64, device=dev)
+            n_pass = min(int(lut[mask.view(torch.uint8).long()].sum().item()), n_local)  # this rank's share
+            gbps = passes * world * n_pass * row_bytes / (ms * 1e-3) / 1e9  # shards are equal up to rounding
             print(json.dumps({
-                "metric": f"batched top-{k} vector QPS (scan shared by {group} queries per pass)", **common,
+                "metric": f"batched top-{k} vector QPS (scan shared by up to {group} queries per pass)", **common,
                 "roofline": {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS * world,
                              "unit": "GB/s", "frac": round(gbps / (HBM_PEAK_GBPS * world), 4), "traffic": None,
                              "passes_per_step": passes},
