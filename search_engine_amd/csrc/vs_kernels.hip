@@ -137,18 +137,24 @@ struct NoDenseFn {
     __device__ __forceinline__ bool wants(uint64_t) const { return false; }
     __device__ __forceinline__ void operator()(uint32_t, uint64_t) const {}
 };
-template <int GROUP, typename ScoreFn, typename DenseFn = NoDenseFn>
+// keep(t): whether the wave takes the t-th of its words at all (a pass over a sample of the
+// words, or over the rest)
+struct EveryWord {
+    __device__ __forceinline__ bool keep(uint64_t) const { return true; }
+};
+template <int GROUP, typename ScoreFn, typename DenseFn = NoDenseFn, typename WordFn = EveryWord>
 __device__ __forceinline__ void scan_masked_slots(const uint64_t* __restrict__ present,
                                                   const uint64_t* __restrict__ cand,
                                                   uint64_t n_slots, uint32_t w, uint32_t W, int lane,
-                                                  uint32_t* queue, ScoreFn&& score, DenseFn&& dense = DenseFn()) {
+                                                  uint32_t* queue, ScoreFn&& score, DenseFn&& dense = DenseFn(),
+                                                  WordFn&& words = WordFn()) {
     static_assert(GROUP <= QCAP - 64, "queue too small");
     const uint64_t n_words = n_slots >> 6;
     const uint64_t my_words = w < n_words ? (n_words - w + W - 1) / W : 0;
     auto fetch_words = [&](uint64_t t0) -> uint64_t {
         const uint64_t t = t0 + (uint64_t)lane;
         uint64_t wd = 0;
-        if (t < my_words) {
+        if (t < my_words && words.keep(t)) {
             const uint64_t wi = (uint64_t)w + t * W;
             wd = present[wi];
             if (cand) wd &= cand[wi];
@@ -552,6 +558,15 @@ struct Mq32Args {
     uint32_t query_stride;    // floats between consecutive queries
     uint32_t n_q;             // 1 .. 32
     uint64_t partial_stride;  // keys between consecutive queries' partial lists
+    const uint64_t* bound;    // nullable: [n_q][k] ascending keys of an earlier pass over the SAMPLE words
+    uint32_t words;           // 0 every word, 1 the sample words only, 2 all but the sample words
+};
+constexpr uint32_t MQ_SAMPLE_PERIOD = 64;  // a wave's t-th word is a sample word iff (t + wave) % 64 == 0
+struct Mq32Words {
+    uint32_t mode, w;
+    __device__ __forceinline__ bool keep(uint64_t t) const {
+        return mode == 0 || (((t + w) % MQ_SAMPLE_PERIOD == 0) == (mode == 1));
+    }
 };
 
 __host__ __device__ inline uint32_t mq32_chunks(uint32_t row_vecs) { return (row_vecs + 7) / 8; }
@@ -612,13 +627,24 @@ __global__ __launch_bounds__(WAVES * 64) void scan_mq32_kernel(Mq32Args m) {
         if (lane == 0) qnorm[q] = n;
     }
     for (int i = lane; i < MQ * k; i += 64) lists[i] = KEY_NONE;
-    if (lane < MQ) tau[lane] = (uint32_t)lane < m.n_q ? KEY_NONE : 0ull;  // 0: nothing is smaller
+    // k-th best so far: the bound of the sample pass if there is one; 0 (nothing is smaller) for a
+    // query the batch lacks
+    if (lane < MQ)
+        tau[lane] = (uint32_t)lane >= m.n_q ? 0ull
+                    : m.bound           ? m.bound[(uint64_t)lane * k + (k - 1)]
+                                        : KEY_NONE;
     __syncthreads();
     const uint32_t col = (uint32_t)lane & 31, half = (uint32_t)lane >> 5;
     const float my_qn = qnorm[col];
     uint64_t* my_list = lists + (size_t)col * k;
 
+#ifdef VS_MQ_STAMP
+    uint64_t cyc_loop = 0, cyc_epi = 0, n_tiles = 0;
+#endif
     auto score_rows = [&](uint32_t head, uint32_t nvalid) {
+#ifdef VS_MQ_STAMP
+        const uint64_t s0 = __builtin_amdgcn_s_memtime();
+#endif
         if (lane < 32) {
             const uint32_t slot = queue[head + ((uint32_t)lane < nvalid ? (uint32_t)lane : nvalid - 1)];
             row_slot[lane] = slot;
@@ -652,43 +678,83 @@ __global__ __launch_bounds__(WAVES * 64) void scan_mq32_kernel(Mq32Args m) {
         for (int d = 0; d < MQ_DEPTH; ++d) request((uint32_t)d, buf[d]);
         const float* arow = stage + col * MQ_STAGE_STRIDE + 4 * half;
         const float* brow = qmat + (size_t)col * qstride + 4 * half;
-        auto to_stage = [&](uint32_t c, const u32x4 (&src)[4]) {
+        // rows i0, i0 + 1 of the four a lane stages / requests; fragment pairs mm0, mm0 + 1
+        auto to_stage2 = [&](uint32_t c, const u32x4 (&src)[4], const int i0) {
             const bool in_row = c * 8 + piece < a.row_vecs;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = i0; i < i0 + 2; ++i)
                 *reinterpret_cast<u32x4*>(stage + (r0 + 8 * i) * MQ_STAGE_STRIDE + piece * 4) =
                     in_row ? src[i] : u32x4{0u, 0u, 0u, 0u};
         };
-        auto fragments = [&](uint32_t c, f32x4 (&fa)[4], f32x4 (&fb)[4]) {
+        auto request2 = [&](uint32_t c, u32x4 (&dst)[4], const int i0) {
+            const uint32_t cc = c < last_chunk ? c : last_chunk;
+            uint32_t v = cc * 8 + piece;
+            v = v < a.row_vecs ? v : a.row_vecs - 1;
+            v -= piece;
 #pragma unroll
-            for (int mm = 0; mm < 4; ++mm) {
-                fa[mm] = *reinterpret_cast<const f32x4*>(arow + 8 * mm);
-                fb[mm] = *reinterpret_cast<const f32x4*>(brow + c * 32 + 8 * mm);
-            }
+            for (int i = i0; i < i0 + 2; ++i) dst[i] = load_vec<true>(base[i] + (int32_t)v);
         };
-        // Software pipeline, one wave per SIMD: while the 16 MFMAs of chunk c run, chunk c + 1 is
-        // already on its way through the staging tile into the other fragment set (LDS executes
-        // a wave's operations in order, so its reads of chunk c are done before the overwrite),
-        // and the rows of chunk c + MQ_DEPTH are on their way from HBM. One step past the last
-        // chunk stages and reads a repeated chunk that no MFMA consumes (the fragment read of
-        // the query block then runs at most 32 floats past a query's row: still inside LDS).
+        auto frag_a2 = [&](f32x4 (&fa)[4], const int mm0) {
+#pragma unroll
+            for (int mm = mm0; mm < mm0 + 2; ++mm) fa[mm] = *reinterpret_cast<const f32x4*>(arow + 8 * mm);
+        };
+        auto frag_b2 = [&](uint32_t c, f32x4 (&fb)[4], const int mm0) {
+#pragma unroll
+            for (int mm = mm0; mm < mm0 + 2; ++mm)
+                fb[mm] = *reinterpret_cast<const f32x4*>(brow + c * 32 + 8 * mm);
+        };
+        // Software pipeline, one wave per SIMD. The 16 MFMAs of chunk c form one dependent chain
+        // (64 cycles each), and a wave issues in order: whatever follows the chain in program
+        // order starts only when its last link has been issued. So the work for the next chunks is
+        // cut into eight pieces of about ten instructions and placed BETWEEN the links, where it
+        // issues in the shadow of the MFMA before it: chunk c + 1 goes through the staging tile
+        // into the other fragment set (LDS executes a wave's operations in order, so the reads of
+        // chunk c were done before the overwrite), the rows of chunk c + MQ_DEPTH are requested
+        // from HBM. One step past the last chunk stages and reads a repeated chunk that no MFMA
+        // consumes (the fragment read of the query block then runs at most 32 floats past a
+        // query's row: still inside LDS).
         f32x4 fa[2][4], fb[2][4];
-        to_stage(0, buf[0]);
+        to_stage2(0, buf[0], 0);
+        to_stage2(0, buf[0], 2);
         request((uint32_t)MQ_DEPTH, buf[0]);
         wave_lds_fence();
-        fragments(0, fa[0], fb[0]);
+        frag_a2(fa[0], 0);
+        frag_a2(fa[0], 2);
+        frag_b2(0, fb[0], 0);
+        frag_b2(0, fb[0], 2);
         auto step = [&](uint32_t c, const int d) {
+            const int nb = (d + 1) % MQ_DEPTH, ns = (d + 1) & 1, cs = d & 1;
+            auto mfma2 = [&](const int mm, const int t0) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cs][mm][t0], fb[cs][mm][t0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cs][mm][t0 + 1], fb[cs][mm][t0 + 1], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
             wave_lds_fence();
-            to_stage(c + 1, buf[(d + 1) % MQ_DEPTH]);
-            request(c + 1 + MQ_DEPTH, buf[(d + 1) % MQ_DEPTH]);
+            mfma2(0, 0);
+            to_stage2(c + 1, buf[nb], 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma2(0, 2);
+            to_stage2(c + 1, buf[nb], 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma2(1, 0);
+            request2(c + 1 + MQ_DEPTH, buf[nb], 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma2(1, 2);
+            request2(c + 1 + MQ_DEPTH, buf[nb], 2);
             wave_lds_fence();
-            fragments(c + 1, fa[(d + 1) & 1], fb[(d + 1) & 1]);
-#pragma unroll
-            for (int mm = 0; mm < 4; ++mm) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[d & 1][mm][t], fb[d & 1][mm][t], acc, 0, 0, 0);
-            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma2(2, 0);
+            frag_a2(fa[ns], 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma2(2, 2);
+            frag_a2(fa[ns], 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma2(3, 0);
+            frag_b2(c + 1, fb[ns], 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma2(3, 2);
+            frag_b2(c + 1, fb[ns], 2);
+            __builtin_amdgcn_sched_barrier(0);
         };
         uint32_t c0 = 0;
         for (; c0 + MQ_DEPTH <= n_chunks; c0 += MQ_DEPTH) {
@@ -699,13 +765,47 @@ __global__ __launch_bounds__(WAVES * 64) void scan_mq32_kernel(Mq32Args m) {
         for (int d = 0; d < MQ_DEPTH; ++d)  // fewer than MQ_DEPTH chunks are left
             if (c0 + (uint32_t)d < n_chunks) step(c0 + (uint32_t)d, d);
         wave_lds_fence();
+#ifdef VS_MQ_STAMP
+        const uint64_t s1 = __builtin_amdgcn_s_memtime();
+#endif
         // lane: query `col`, rows (e & 3) + 8 (e >> 2) + 4 half
         uint64_t key[16];
+        if (METRIC == VS_ANGULAR) {
+            // Most rows lose against the query's k-th best d_k. d < d_k  <=>  <p,q> > |p| |q| (1 - 2 d_k), so
+            // one multiply-add per score on the accumulator decides (with a margin of 1e-6 |q|, so that
+            // rounding can only admit too many); the formula itself, with its division, is evaluated
+            // for the survivors only. Anything that does not compare (NaN) survives.
+            const uint64_t tk = tau[col];
+            const float dk = f32_from_orderable((uint32_t)(tk >> 32));
+            float c2 = (1.0f - 2.0f * dk) * my_qn - 1e-6f * my_qn;
+            if (tk == KEY_NONE || !(c2 == c2)) c2 = -__builtin_inff();
+            uint32_t alive = 0;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const uint32_t r = (uint32_t)((e & 3) + 8 * (e >> 2)) + 4 * half;
-            const float d = METRIC == VS_ANGULAR ? angular_distance(acc[e], row_norm[r], my_qn) : -acc[e];
-            key[e] = r < nvalid ? make_key(f32_orderable(d), a.docid_base + row_slot[r]) : KEY_NONE;
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 pn4 = *reinterpret_cast<const f32x4*>(row_norm + 8 * g + 4 * half);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float t = __builtin_fmaf(-pn4[i], c2, acc[4 * g + i]);
+                    if (!(t < 0.0f) && (uint32_t)(8 * g + i) + 4 * half < nvalid) alive |= 1u << (4 * g + i);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) key[e] = KEY_NONE;
+            if (__ballot(alive != 0)) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const uint32_t r = (uint32_t)((e & 3) + 8 * (e >> 2)) + 4 * half;
+                    if ((alive >> e) & 1)
+                        key[e] = make_key(f32_orderable(angular_distance(acc[e], row_norm[r], my_qn)),
+                                          a.docid_base + row_slot[r]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t r = (uint32_t)((e & 3) + 8 * (e >> 2)) + 4 * half;
+                key[e] = r < nvalid ? make_key(f32_orderable(-acc[e]), a.docid_base + row_slot[r]) : KEY_NONE;
+            }
         }
 #pragma unroll 1
         for (uint32_t turn = 0; turn < 2; ++turn) {
@@ -720,16 +820,31 @@ __global__ __launch_bounds__(WAVES * 64) void scan_mq32_kernel(Mq32Args m) {
                             --pos;
                         }
                         my_list[pos] = key[e];
-                        t = my_list[k - 1];
+                        t = min_u64(t, my_list[k - 1]);
                     }
                 }
                 tau[col] = t;
             }
             wave_lds_fence();
         }
+#ifdef VS_MQ_STAMP
+        const uint64_t s2 = __builtin_amdgcn_s_memtime();
+        cyc_loop += s1 - s0;
+        cyc_epi += s2 - s1;
+        ++n_tiles;
+#endif
     };
 
-    scan_masked_slots<32>(a.present, a.cand, a.n_slots, w, W, lane, queue, score_rows);
+#ifdef VS_MQ_STAMP
+    const uint64_t t0 = __builtin_amdgcn_s_memtime(), r0_ = __builtin_amdgcn_s_memrealtime();
+#endif
+    scan_masked_slots<32>(a.present, a.cand, a.n_slots, w, W, lane, queue, score_rows, NoDenseFn(),
+                          Mq32Words{m.words, w});
+#ifdef VS_MQ_STAMP
+    const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1_ = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == 7 && threadIdx.x == 0)
+        printf("mq32 clk %llu real %llu -> %.1f MHz; tiles %llu loop %llu epi %llu per tile\n", (unsigned long long)(t1 - t0), (unsigned long long)(r1_ - r0_), (double)(t1 - t0) / (double)(r1_ - r0_) * 100.0, (unsigned long long)n_tiles, (unsigned long long)(cyc_loop / n_tiles), (unsigned long long)(cyc_epi / n_tiles));
+#endif
     __syncthreads();
     // thread q of the workgroup merges the four waves' lists of query q
     if (threadIdx.x < m.n_q) {
@@ -737,7 +852,12 @@ __global__ __launch_bounds__(WAVES * 64) void scan_mq32_kernel(Mq32Args m) {
         uint32_t at[WAVES];
 #pragma unroll
         for (int v = 0; v < WAVES; ++v) at[v] = 0;
-        uint64_t* out = a.partial + (uint64_t)threadIdx.x * m.partial_stride;
+        // list-major: list `blockIdx.x` of the query; the sample pass's list rides along as list gridDim.x
+        uint64_t* out = a.partial + (uint64_t)threadIdx.x * m.partial_stride + (uint64_t)blockIdx.x * k;
+        if (m.bound && blockIdx.x == 0)
+            for (int r = 0; r < k; ++r)
+                a.partial[(uint64_t)threadIdx.x * m.partial_stride + (uint64_t)gridDim.x * k + r] =
+                    m.bound[(uint64_t)threadIdx.x * k + r];
         for (int r = 0; r < k; ++r) {
             uint64_t best = KEY_NONE;
             int from = 0;
@@ -753,7 +873,7 @@ __global__ __launch_bounds__(WAVES * 64) void scan_mq32_kernel(Mq32Args m) {
 #pragma unroll
             for (int v = 0; v < WAVES; ++v)
                 if (v == from && best != KEY_NONE) ++at[v];
-            out[(uint64_t)r * gridDim.x + blockIdx.x] = best;
+            out[r] = best;
         }
     }
 }
@@ -1334,8 +1454,13 @@ uint32_t scan_mq32_blocks(const SlabView& s) {
     const uint64_t want = (s.n_slots + 1023) / 1024;
     return (uint32_t)(want < 1 ? 1 : want > NUM_CUS ? NUM_CUS : want);  // the query block fills a CU's LDS
 }
+// Stores large enough that a bound from 1/64 of the words pays for a pass of its own: with it the
+// main pass inserts next to nothing (without, every tile's epilogue runs the divergent insertion).
+static bool mq32_two_passes(const SlabView& s) { return s.n_slots >= (1u << 20); }
 uint64_t scan_mq32_partial_bytes(const SlabView& s, uint32_t k) {
-    return (uint64_t)MQ * scan_mq32_blocks(s) * k * sizeof(uint64_t);
+    const uint64_t lists = (uint64_t)MQ * (scan_mq32_blocks(s) + 1) * k;  // main pass (+ the sample's list)
+    const uint64_t sample = mq32_two_passes(s) ? (uint64_t)MQ * scan_mq32_blocks(s) * k + (uint64_t)MQ * k : 0;
+    return (lists + sample) * sizeof(uint64_t);
 }
 
 hipError_t launch_scan_mq32(const SlabView& s, const float* d_queries, uint32_t query_stride,
@@ -1346,13 +1471,13 @@ hipError_t launch_scan_mq32(const SlabView& s, const float* d_queries, uint32_t 
         (s.metric == VS_ANGULAR && !s.norms))
         return hipErrorInvalidValue;
     const uint32_t blocks = scan_mq32_blocks(s);
+    const bool two = mq32_two_passes(s);
     Mq32Args m;
     m.s.rows = reinterpret_cast<const u32x4*>(s.rows);
     m.s.norms = s.norms;
     m.s.present = s.present;
     m.s.cand = cand;
     m.s.query = d_queries;
-    m.s.partial = partial;
     m.s.n_slots = s.n_slots;
     m.s.row_vecs = s.row_vecs;
     m.s.dim = s.dim;
@@ -1361,17 +1486,34 @@ hipError_t launch_scan_mq32(const SlabView& s, const float* d_queries, uint32_t 
     m.s.metric = s.metric;
     m.query_stride = query_stride;
     m.n_q = n_q;
-    m.partial_stride = (uint64_t)blocks * k;
     const size_t lds = mq32_lds_bytes(s.row_vecs, k);
     void (*kernel)(Mq32Args) = s.metric == VS_ANGULAR ? scan_mq32_kernel<VS_ANGULAR> : scan_mq32_kernel<VS_DOT>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+    // workspace: main lists [MQ][blocks + 1][k] | sample lists [MQ][blocks][k] | sample top-k [MQ][k]
+    uint64_t* main_lists = partial;
+    uint64_t* sample_lists = partial + (uint64_t)MQ * (blocks + 1) * k;
+    uint64_t* sample_top = sample_lists + (uint64_t)MQ * blocks * k;
+    if (two) {
+        m.s.partial = sample_lists;
+        m.partial_stride = (uint64_t)blocks * k;
+        m.bound = nullptr;
+        m.words = 1;
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(WAVES * 64), lds, stream, m);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        e = launch_merge_batch(sample_lists, blocks, k, 1, n_q, (uint64_t)blocks * k, k, s.metric, sample_top,
+                               nullptr, nullptr, nullptr, stream);
+        if (e != hipSuccess) return e;
+    }
+    m.s.partial = main_lists;
+    m.partial_stride = (uint64_t)(blocks + 1) * k;
+    m.bound = two ? sample_top : nullptr;
+    m.words = two ? 2 : 0;
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(WAVES * 64), lds, stream, m);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    return launch_merge_batch(partial, blocks, 1, blocks, n_q, (uint64_t)blocks * k, k, s.metric, out_keys,
-                              out_ids, out_dist, out_n, stream);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    return launch_merge_batch(main_lists, blocks + (two ? 1 : 0), k, 1, n_q, (uint64_t)(blocks + 1) * k, k,
+                              s.metric, out_keys, out_ids, out_dist, out_n, stream);
 }
 
 hipError_t launch_merge(const uint64_t* keys, uint32_t n_lists, uint64_t list_stride,

@@ -617,3 +617,37 @@ def test_batches_on_the_f32_matrix_cores(gpu_ctx, metric_name, dim, k, n_q):
                 assert at[1] == at[0] + 1 and at[2] == at[0] + 2 and dist[at[0]] == dist[at[1]] == dist[at[2]]
     finally:
         store.destroy()
+
+
+def test_f32_matrix_core_batches_with_a_sample_pass(gpu_ctx):
+    """Stores of a million slots or more: a first pass over 1/64 of the mask words gives every
+    query a bound, the main pass covers the rest. Same parity rules; the sample's own
+    neighbours (a planted row inside a sample word) and rows outside it both have to show up."""
+    from search_engine_amd import abi
+    n, dim, k, n_q = 1_100_000, 24, 10, 40
+    rng = np.random.default_rng(77)
+    vectors = rng.standard_normal((n, dim), dtype=np.float32)
+    queries = rng.standard_normal((n_q, dim), dtype=np.float32)
+    vectors[0] = queries[0] * 3.0          # word 0 of wave 0 is a sample word
+    vectors[999_999] = queries[1] * 0.5
+    docids = np.arange(n, dtype=np.uint32)
+    _next_index[0] += 1
+    store = gpu_ctx.create_store(_next_index[0], dim, n)
+    try:
+        for lo in range(0, n, 1 << 18):
+            store.upload(docids[lo:lo + (1 << 18)], vectors[lo:lo + (1 << 18)])
+        store.seal()
+        norms = oracle.norms(vectors)
+        for pass_percent in (100, 5):
+            mask = facet_mask(n, pass_percent) if pass_percent < 100 else None
+            n_cand = n if mask is None else int(oracle.mask_to_bool(mask, n).sum())
+            batch = store.search_batch(queries, k, mask)
+            o_ids, _, o_n, _ = oracle.nns_batch_mt(vectors, queries, k, mask=mask, norms=norms)
+            for j, (ids, dist) in enumerate(batch):
+                cand = sorted(set(ids.tolist()) | set(o_ids[j].tolist()))
+                d64 = dict(zip(cand, oracle.all_distances_f64(vectors[cand], queries[j]).tolist()))
+                assert check_hits(ids, dist, o_ids[j], d64, k, n_cand) <= 2
+            if pass_percent == 100:
+                assert batch[0][0][0] == 0 and batch[1][0][0] == 999_999
+    finally:
+        store.destroy()
