@@ -528,8 +528,7 @@ __global__ __launch_bounds__(WAVES * 64) void scan_multi_kernel(MultiArgs m) {
 // v_mfma_f32_32x32x2_f32 multiplies exact f32 operands and accumulates like a chain of fmaf,
 // at 1/16 of the bf16 rate: 2 * 32 * dim flop per row are about what a CU can do in the row's
 // HBM time, so THIRTY-TWO queries ride on one pass over an f32 slab (measured on 10 M x 768:
-// 7.3 ms per pass against 4.4 ms for a single-query pass; a build without the row loads takes
-// 5.4 ms, i.e. the matrix cores at the clock they hold under this load are the floor).
+// 6.8 ms per pass against 4.4 ms for a single-query pass).
 // One wave = one 32-row x 32-query tile:
 //   * the 32 queries sit in LDS for the whole kernel (row-major, 4 floats of padding);
 //   * rows come from the candidate queue, so a filter skips rows exactly as in the
