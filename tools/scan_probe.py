@@ -78,7 +78,7 @@ def main():
                 got = keys.cpu().numpy().tolist()
                 ref = ref or got
                 assert got == ref, "schedules disagree"
-                if r:  # round 0 warms up
+                if r:  # the first repetition warms up
                     times[v].append(e0.elapsed_time(e1) / args.reps)
         for v in variants:
             t = np.array(times[v])
