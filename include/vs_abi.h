@@ -197,8 +197,9 @@ int32_t vs_search_mask(vs_store* s, const float* query, uint32_t dim, uint32_t k
  * summation order: distances equal vs_search's up to rounding). Otherwise groups
  * of eight (f32 rows of up to 768 dimensions) or four queries (f32 up to 1536,
  * bf16 up to 1536 dimensions) share each pass over the rows when k <= 128, and
- * every query's result is bit-identical to its own vs_search; anything else is
- * one scan per query. No reference counterpart (the reference searches one vector per
+ * every query's result is bit-identical to its own vs_search; on binary stores
+ * (rows of up to 2048 bits, k <= 128) four queries share a pass, results equal
+ * to vs_search's; anything else is one scan per query. No reference counterpart (the reference searches one vector per
  * request). */
 int32_t vs_search_batch(vs_store* s, const float* queries, uint32_t n_q, uint32_t dim,
                         uint32_t k, const uint64_t* mask_words, uint64_t n_mask_words,

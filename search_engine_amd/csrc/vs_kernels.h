@@ -77,6 +77,15 @@ hipError_t launch_scan_hamming(const SlabView& s, const void* d_query, const uin
                                uint32_t* out_ids, float* out_dist, uint32_t* out_n,
                                const ScanTuning& t, hipStream_t stream);
 
+// Up to four packed queries (query_stride 16-byte vectors apart) in one pass over a VS_BIN1 slab
+// of rows of up to 2048 bits, k <= 128 (scan_hamming_multi_serves). `partial` needs four times
+// scan_partial_bytes. Outputs as launch_scan_multi; results equal launch_scan_hamming's exactly.
+bool scan_hamming_multi_serves(const SlabView& s, uint32_t k);
+hipError_t launch_scan_hamming_multi(const SlabView& s, const void* d_queries, uint32_t query_stride,
+                                     uint32_t n_q, const uint64_t* cand, uint32_t k, uint64_t* partial,
+                                     uint64_t* out_keys, uint32_t* out_ids, float* out_dist,
+                                     uint32_t* out_n, const ScanTuning& t, hipStream_t stream);
+
 // Batched angular scan of a VS_BF16 slab on the matrix cores (vs_batch.hip): up to
 // 256 queries (f32 [n_q][dim] in device memory, rounded to bf16 by a prologue
 // kernel) share one pass over the rows. k <= VS_BATCH_MAX_K. `workspace` needs

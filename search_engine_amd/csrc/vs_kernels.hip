@@ -1038,6 +1038,122 @@ __global__ __launch_bounds__(WAVES * 64) void scan_hamming_kernel(HammingArgs a)
     finish_block(top, smem, k, wib, lane, a.partial);
 }
 
+// ---- Hamming scan, four queries per pass ------------------------------------------------
+//
+// vs_search_batch on binary stores: four queries share every row read. The quad schedule of
+// the single-query scan (four lanes per row, 16 rows per pass); each lane counts its share of
+// the row against all four queries, and the two reduction steps transpose while they add, so
+// that lane `sub` of a quad ends up with the whole distance of ONE query (2 (sub & 1) +
+// (sub >> 1)) and compares it with that query's k-th best itself. Distances are integers:
+// results equal vs_search's exactly.
+constexpr int HQ = 4;
+struct HammingMultiArgs {
+    HammingArgs s;            // query = first query; partial = first query's lists
+    uint32_t query_stride;    // 16-byte vectors between consecutive queries
+    uint32_t n_q;             // 1 .. HQ
+    uint64_t partial_stride;  // keys between consecutive queries' partial lists
+};
+
+template <int NI, int U>
+__global__ __launch_bounds__(WAVES * 64) void scan_hamming_multi_kernel(HammingMultiArgs m) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const HammingArgs& a = m.s;
+    const int lane = threadIdx.x & 63;
+    const int quad = lane >> 2, sub = lane & 3;
+    const uint32_t wib = uniform_u32(threadIdx.x >> 6);
+    const uint32_t W = gridDim.x * WAVES;
+    const uint32_t w = blockIdx.x * WAVES + wib;
+    const int k = (int)a.k;
+    uint32_t* queue =
+        reinterpret_cast<uint32_t*>(smem + (size_t)HQ * WAVES * k * 8) + (size_t)wib * QCAP;
+    WaveTopK top[HQ];
+#pragma unroll
+    for (int q = 0; q < HQ; ++q)
+        top[q].init(reinterpret_cast<uint64_t*>(smem) + ((size_t)q * WAVES + wib) * k, k, lane);
+
+    // this lane's share of every query: vectors sub, sub + 4, ...
+    u32x4 qv[HQ][NI];
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) {
+        const u32x4* src = a.query + (size_t)(q < (int)m.n_q ? q : 0) * m.query_stride;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const uint32_t p = (uint32_t)(i * 4 + sub);
+            qv[q][i] = p < a.row_vecs ? src[p] : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    const bool b0 = sub & 1, b1 = sub & 2;
+    const int mine = (b0 ? 2 : 0) + (b1 ? 1 : 0);
+    // k-th best key of this lane's query so far; 0 (nothing is smaller) for a query the batch lacks
+    uint64_t my_tau = (uint32_t)mine < m.n_q ? KEY_NONE : 0ull;
+    wave_lds_fence();
+
+    auto score_rows = [&](uint32_t head, uint32_t nvalid) {
+        uint32_t slot[U];
+        bool valid[U];
+        u32x4 x[U][NI];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t r = (uint32_t)(u * 16 + quad);
+            valid[u] = r < nvalid;
+            slot[u] = queue[head + (valid[u] ? r : 0u)];
+            const u32x4* rp = a.rows + (uint64_t)slot[u] * a.row_vecs;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const uint32_t p = (uint32_t)(i * 4 + sub);
+                if (i < NI - 1 || p < a.row_vecs) {
+                    x[u][i] = load_vec<true>(rp + p);
+                } else {
+                    x[u][i] = u32x4{0u, 0u, 0u, 0u};
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint32_t cnt[HQ];
+#pragma unroll
+            for (int q = 0; q < HQ; ++q) {
+                cnt[q] = 0;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) cnt[q] += (uint32_t)__popc(x[u][i][j] ^ qv[q][i][j]);
+                }
+            }
+            // lane pairs: the even lane keeps queries 0 and 1, the odd one 2 and 3; then the halves
+            // of a quad split again
+            const uint32_t pa = (b0 ? cnt[2] : cnt[0]) + dpp_u32<0xB1, 0xF>(b0 ? cnt[0] : cnt[2]);
+            const uint32_t pb = (b0 ? cnt[3] : cnt[1]) + dpp_u32<0xB1, 0xF>(b0 ? cnt[1] : cnt[3]);
+            const uint32_t d = (b1 ? pb : pa) + dpp_u32<0x4E, 0xF>(b1 ? pa : pb);
+            const uint64_t key = make_key(d, a.docid_base + slot[u]);
+            uint64_t hits = __ballot(valid[u] && key < my_tau);
+            if (hits) {
+#pragma unroll
+                for (int q = 0; q < HQ; ++q) {
+                    // query q is spoken for by lane ((q & 1) << 1 | q >> 1) of every quad
+                    const uint64_t lanes_q = 0x1111111111111111ull << (((q & 1) << 1) | (q >> 1));
+                    uint64_t hq = hits & lanes_q;
+                    while (hq) {
+                        const int src = __builtin_ctzll(hq);
+                        top[q].insert(readlane_u64(key, src));
+                        if (mine == q) my_tau = top[q].tau;
+                        hq &= hq - 1;
+                        hq &= __ballot(valid[u] && key < my_tau);
+                    }
+                }
+            }
+        }
+    };
+
+    scan_masked_slots<16 * U>(a.present, a.cand, a.n_slots, w, W, lane, queue, score_rows);
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) {
+        if ((uint32_t)q < m.n_q)
+            finish_block(top[q], smem + (size_t)q * WAVES * k * 8, k, wib, lane,
+                         a.partial + (uint64_t)q * m.partial_stride);
+    }
+}
+
 // ---- merge of sorted key lists ------------------------------------------------
 
 // One workgroup per query: blockIdx.x selects the query's key lists
@@ -1513,6 +1629,44 @@ hipError_t launch_scan_mq32(const SlabView& s, const float* d_queries, uint32_t 
     if ((e = hipGetLastError()) != hipSuccess) return e;
     return launch_merge_batch(main_lists, blocks + (two ? 1 : 0), k, 1, n_q, (uint64_t)(blocks + 1) * k, k,
                               s.metric, out_keys, out_ids, out_dist, out_n, stream);
+}
+
+bool scan_hamming_multi_serves(const SlabView& s, uint32_t k) {
+    return s.dtype == VS_BIN1 && k >= 1 && k <= (uint32_t)WaveTopK::REG_K && s.row_vecs <= 16;
+}
+
+hipError_t launch_scan_hamming_multi(const SlabView& s, const void* d_queries, uint32_t query_stride,
+                                     uint32_t n_q, const uint64_t* cand, uint32_t k, uint64_t* partial,
+                                     uint64_t* out_keys, uint32_t* out_ids, float* out_dist,
+                                     uint32_t* out_n, const ScanTuning& t, hipStream_t stream) {
+    if (!scan_hamming_multi_serves(s, k) || n_q == 0 || n_q > (uint32_t)HQ || (s.n_slots & 63) ||
+        s.n_slots == 0)
+        return hipErrorInvalidValue;
+    const uint32_t blocks = scan_grid_blocks(s, t, cand != nullptr);
+    HammingMultiArgs m;
+    m.s.rows = reinterpret_cast<const u32x4*>(s.rows);
+    m.s.present = s.present;
+    m.s.cand = cand;
+    m.s.query = reinterpret_cast<const u32x4*>(d_queries);
+    m.s.partial = partial;
+    m.s.n_slots = s.n_slots;
+    m.s.row_vecs = s.row_vecs;
+    m.s.docid_base = s.docid_base;
+    m.s.k = k;
+    m.query_stride = query_stride;
+    m.n_q = n_q;
+    m.partial_stride = (uint64_t)blocks * k;
+    const size_t lds = (size_t)HQ * WAVES * k * 8 + (size_t)WAVES * QCAP * 4;
+    const dim3 grid(blocks), block(WAVES * 64);
+    const uint32_t ni = (s.row_vecs + 3) / 4;
+    if (ni <= 1) hipLaunchKernelGGL((scan_hamming_multi_kernel<1, 4>), grid, block, lds, stream, m);
+    else if (ni <= 2) hipLaunchKernelGGL((scan_hamming_multi_kernel<2, 4>), grid, block, lds, stream, m);
+    else if (ni <= 3) hipLaunchKernelGGL((scan_hamming_multi_kernel<3, 4>), grid, block, lds, stream, m);
+    else hipLaunchKernelGGL((scan_hamming_multi_kernel<4, 2>), grid, block, lds, stream, m);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_merge_batch(partial, blocks, 1, blocks, n_q, (uint64_t)blocks * k, k, VS_HAMMING, out_keys,
+                              out_ids, out_dist, out_n, stream);
 }
 
 hipError_t launch_merge(const uint64_t* keys, uint32_t n_lists, uint64_t list_stride,

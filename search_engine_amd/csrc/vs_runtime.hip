@@ -357,9 +357,11 @@ int32_t run_many_and_fetch(vs_store* s, Workspace* ws, const float* h_queries, u
     const vs::ScanTuning& t = s->ctx->tuning;
     // several queries share every pass over the rows where one of the multi-query scans serves the store
     const bool shared = shared_pass_serves(v, k);
+    const bool shared_bits = vs::scan_hamming_multi_serves(v, k);  // binary rows: four queries per pass
     if (int32_t rc = grow(&ws->d_partial, &ws->partial_bytes,
-                          shared ? (size_t)shared_pass_partial_bytes(v, k, t)
-                                 : (size_t)vs::scan_partial_bytes(v, k, t)))
+                          shared        ? (size_t)shared_pass_partial_bytes(v, k, t)
+                          : shared_bits ? (size_t)vs::scan_partial_bytes(v, k, t) * 4
+                                        : (size_t)vs::scan_partial_bytes(v, k, t)))
         return rc;
     const size_t chunk_q = 64;
     const bool bin = s->dtype == VS_BIN1;
@@ -392,6 +394,12 @@ int32_t run_many_and_fetch(vs_store* s, Workspace* ws, const float* h_queries, u
                                                  (uint32_t)(q_stride / 4), m, d_cand, k, ws->d_partial, nullptr,
                                                  d_ids, d_dist, d_n, ws->stream))
                 return rc;
+        } else if (shared_bits) {
+            for (uint32_t i = 0; i < m; i += 4)
+                HIP_TRY(vs::launch_scan_hamming_multi(v, ws->d_batch + i * q_stride, (uint32_t)(q_stride / 16),
+                                                      m - i < 4 ? m - i : 4, d_cand, k, ws->d_partial, nullptr,
+                                                      d_ids + (size_t)i * k, d_dist + (size_t)i * k, d_n + i, t,
+                                                      ws->stream));
         } else {
             for (uint32_t i = 0; i < m; ++i)
                 if (int32_t rc = launch_scan(s, ws->d_batch + i * q_stride, d_cand, k, ws->d_partial, nullptr,

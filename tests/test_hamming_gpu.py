@@ -111,3 +111,33 @@ def test_metric_and_dtype_must_agree(gpu_ctx):
         with pytest.raises(abi.VsError) as e:
             gpu_ctx.create_store(0x4FFF, 64, 100, dtype=dtype, metric=metric)
         assert e.value.code == abi.VS_E_INVALID_ARG
+
+
+@pytest.mark.parametrize("dim,k", [(1, 3), (64, 10), (300, 100), (1024, 128), (1536, 100), (2048, 10),
+                                   (4096, 10),    # beyond the shared-pass scan: one scan per query
+                                   (1536, 129)])  # k beyond its register lists: likewise
+def test_batches_share_each_pass_between_four_queries(gpu_ctx, dim, k):
+    """vs_search_batch on a binary store: four queries per pass over the rows; every query's list
+    equals the oracle's (and so vs_search's) exactly, for batch sizes that do and do not fill
+    the last group, with and without a filter, with holes and duplicated rows (ties by docid)."""
+    n = 4000
+    rng = np.random.default_rng(dim + k)
+    docids = np.sort(rng.choice(n + 600, n, replace=False)).astype(np.uint32)
+    vectors = synthetic_vectors(n, dim, 700 + dim)
+    vectors[21] = vectors[20]
+    queries = synthetic_vectors(9, dim, 701 + dim)
+    queries[1] = vectors[20]
+    store = make_bin_store(gpu_ctx, vectors, docids)
+    codes = oracle.binarize(vectors)
+    try:
+        for mask in (None, facet_mask(n + 600, 25)):
+            expect = [oracle.hamming_topk(codes, oracle.binarize(q[None, :])[0], k, docids=docids, mask=mask)
+                      for q in queries]
+            for n_q in (1, 2, 3, 4, 5, 8, 9):
+                batch = store.search_batch(queries[:n_q], k, mask)
+                assert len(batch) == n_q
+                for (ids, dist), (o_ids, o_dist) in zip(batch, expect):
+                    assert ids.tolist() == o_ids.tolist()
+                    assert dist.tolist() == o_dist.astype(np.float32).tolist()
+    finally:
+        store.destroy()

@@ -30,16 +30,21 @@ def main():
     dev = torch.device("cuda", 0)
     ctx = abi.Context(0)
     n = -(-args.docs // 64) * 64
-    dtype = {"f32": abi.VS_F32, "bf16": abi.VS_BF16}[args.dtype]
-    metric = {"angular": abi.VS_ANGULAR, "euclidean": abi.VS_EUCLIDEAN, "dot": abi.VS_DOT}[args.metric]
+    binary = args.dtype == "bin1"  # Hamming store: four queries share each pass
+    dtype = {"f32": abi.VS_F32, "bf16": abi.VS_BF16, "bin1": abi.VS_BIN1}[args.dtype]
+    metric = abi.VS_HAMMING if binary else {"angular": abi.VS_ANGULAR, "euclidean": abi.VS_EUCLIDEAN,
+                                            "dot": abi.VS_DOT}[args.metric]
     store = ctx.create_store(0, args.dim, n, dtype=dtype, metric=metric)
     gen = torch.Generator(device=dev)
     gen.manual_seed(0xC0FFEE)
     stream = torch.cuda.current_stream().cuda_stream
-    tdtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
+    tdtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     for lo in range(0, args.docs, 1 << 18):
         m = min(1 << 18, args.docs - lo)
-        rows = torch.randn(m, args.dim, generator=gen, device=dev).to(tdtype)
+        if binary:
+            rows = torch.randint(-2**63, 2**63 - 1, (m, args.dim // 64), generator=gen, device=dev, dtype=torch.int64)
+        else:
+            rows = torch.randn(m, args.dim, generator=gen, device=dev).to(tdtype)
         store.upload_device(lo, rows.data_ptr(), m, stream)
         torch.cuda.synchronize()
     store.seal()
@@ -69,7 +74,7 @@ def main():
                 assert len(set(a.tolist()) ^ set(c.tolist())) <= 2
             else:
                 assert a.tolist() == c.tolist() and b.tolist() == d.tolist()
-        group = 32 if mfma else 8 if args.dtype == "f32" and args.dim <= 768 else 4
+        group = 32 if mfma else 8 if args.dtype == "f32" and args.dim <= 768 else 4  # (4 also for binary rows)
         passes = -(-args.queries // group)
         print(f"p={p:3d}%  batch of {args.queries}: {1e3 * t_batch:8.3f} ms = {args.queries / t_batch:9.1f} queries/s, "
               f"{1e3 * t_batch / passes:7.3f} ms per pass = {algo / (t_batch / passes) / 1e9:7.1f} GB/s;  "
