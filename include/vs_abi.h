@@ -236,6 +236,9 @@ int32_t vs_search_device(vs_store* s, const void* d_query, uint32_t dim, uint32_
  *   - otherwise, f32 rows of up to 1536 dimensions or bf16 rows of up to 1536,
  *     k <= 128: groups of eight (f32, up to 768 dimensions) or four queries share
  *     a pass, each list bit-identical to vs_search_device's;
+ *   - VS_BIN1 stores (rows of up to 2048 bits, k <= 128): d_queries holds n_q
+ *     PACKED queries of vs_store_row_bytes bytes each (as vs_search_device takes
+ *     one); four share a pass, lists equal to vs_search_device's;
  *   - anything else: VS_E_INVALID_ARG (use vs_search_device per query).
  * No reference counterpart (the reference searches one vector per request). */
 int32_t vs_search_batch_workspace_bytes(vs_store* s, uint32_t k, uint64_t* bytes);

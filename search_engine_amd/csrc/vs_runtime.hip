@@ -1025,6 +1025,10 @@ extern "C" int32_t vs_search_batch_workspace_bytes(vs_store* s, uint32_t k, uint
         *bytes = vs::batch_workspace_bytes(v, k);
         return VS_OK;
     }
+    if (vs::scan_hamming_multi_serves(v, k)) {
+        *bytes = vs::scan_partial_bytes(v, k, s->ctx->tuning) * 4;
+        return VS_OK;
+    }
     if (!shared_pass_serves(v, k))
         return fail(VS_E_INVALID_ARG,
                     "no batched scan for this store and k = %u (angular bf16 rows with k <= %u; f32 rows "
@@ -1052,6 +1056,17 @@ extern "C" int32_t vs_search_batch_device(vs_store* s, const float* d_queries, u
     if (on_matrix_cores(s, k)) {
         HIP_TRY(vs::launch_scan_batch_bf16(v, d_queries, n_q, d_mask_words, k, d_workspace, d_out_keys,
                                            nullptr, nullptr, nullptr, stream));
+        return VS_OK;
+    }
+    if (vs::scan_hamming_multi_serves(v, k)) {
+        // binary store: d_queries holds n_q packed queries, vs_store_row_bytes bytes each
+        const unsigned char* bits = reinterpret_cast<const unsigned char*>(d_queries);
+        for (uint32_t i = 0; i < n_q; i += 4)
+            HIP_TRY(vs::launch_scan_hamming_multi(v, bits + (size_t)i * s->row_bytes(), s->row_vecs,
+                                                  n_q - i < 4 ? n_q - i : 4, d_mask_words, k,
+                                                  static_cast<uint64_t*>(d_workspace),
+                                                  d_out_keys + (size_t)i * k, nullptr, nullptr, nullptr,
+                                                  s->ctx->tuning, stream));
         return VS_OK;
     }
     if (!shared_pass_serves(v, k))

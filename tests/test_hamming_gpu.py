@@ -141,3 +141,34 @@ def test_batches_share_each_pass_between_four_queries(gpu_ctx, dim, k):
                     assert dist.tolist() == o_dist.astype(np.float32).tolist()
     finally:
         store.destroy()
+
+
+def test_batch_device_entry_point_on_a_binary_store(gpu_ctx):
+    """vs_search_batch_device with packed queries: the keys vs_search_device gives, query by query."""
+    import torch
+    n, dim, k, n_q = 6000, 1536, 100, 7
+    vectors = synthetic_vectors(n, dim, 811)
+    queries = synthetic_vectors(n_q, dim, 812)
+    mask = facet_mask(n, 60)
+    store = make_bin_store(gpu_ctx, vectors)
+    try:
+        dev = torch.device("cuda:0")
+        stream = torch.cuda.current_stream().cuda_stream
+        packed = torch.from_numpy(oracle.binarize(queries).view(np.int64).copy()).to(dev)  # [n_q][24]
+        assert packed.shape[1] * 8 == store.row_bytes
+        d_mask = torch.from_numpy(mask[: -(-n // 64)].view(np.int64).copy()).to(dev)
+        bws = torch.empty(store.batch_workspace_bytes(k), dtype=torch.uint8, device=dev)
+        bkeys = torch.empty(n_q * k, dtype=torch.int64, device=dev)
+        store.search_batch_device(packed.data_ptr(), n_q, dim, k, d_mask.data_ptr(), bws.data_ptr(),
+                                  bkeys.data_ptr(), stream)
+        sws = torch.empty(store.workspace_bytes(k), dtype=torch.uint8, device=dev)
+        skeys = torch.empty(k, dtype=torch.int64, device=dev)
+        for j in range(n_q):
+            store.search_device(packed[j].data_ptr(), dim, k, d_mask.data_ptr(), sws.data_ptr(),
+                                skeys.data_ptr(), stream)
+            torch.cuda.synchronize()
+            assert bkeys[j * k:(j + 1) * k].tolist() == skeys.tolist()
+            ids, _ = store.search(queries[j], k, mask)
+            assert (skeys.cpu().numpy().view(np.uint64) & 0xFFFFFFFF).tolist() == ids.tolist()
+    finally:
+        store.destroy()
