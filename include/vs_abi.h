@@ -225,6 +225,21 @@ int32_t vs_search_device(vs_store* s, const void* d_query, uint32_t dim, uint32_
                          const uint64_t* d_mask_words, void* d_workspace, uint64_t* d_out_keys,
                          void* hip_stream);
 
+/* No counterpart in the reference. vs_search_device for callers that cannot
+ * allocate device memory or pass a workspace: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc. Same arguments and the same
+ * d_out_keys as vs_search_device, minus d_workspace: the scan's partial lists go
+ * to a static array of VS_NOALLOC_SCRATCH_BYTES in device memory (one per GPU,
+ * held until the process ends). The call allocates nothing and frees nothing.
+ * Limit: (workgroups of the scan, at most 512 by default) * k * 8 bytes must fit,
+ * i.e. k <= 256 on a large store; beyond that VS_E_CAPACITY. Every call on one
+ * GPU shares the array: calls whose kernels can overlap on that GPU (different
+ * streams, or several threads) race; issue them on one stream. */
+#define VS_NOALLOC_SCRATCH_BYTES (1u << 20)
+int32_t vs_search_device_noalloc(vs_store* s, const void* d_query, uint32_t dim, uint32_t k,
+                                 const uint64_t* d_mask_words, uint64_t* d_out_keys,
+                                 void* hip_stream);
+
 /* Batched form: `n_q` <= VS_BATCH_MAX_QUERIES queries (f32 [n_q][dim] in device
  * memory) under one candidate mask; d_out_keys receives n_q lists of k keys.
  *   - angular VS_BF16 stores, k <= VS_BATCH_MAX_K: ONE pass over the rows on the

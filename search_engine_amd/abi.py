@@ -59,6 +59,7 @@ SIGNATURES = {
     "vs_search_mask": [_vp, _f32p, _u32, _u32, _vp, _u32p, _f32p, _u32p],
     "vs_search_workspace_bytes": [_vp, _u32, _u64p],
     "vs_search_device": [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp],
+    "vs_search_device_noalloc": [_vp, _vp, _u32, _u32, _vp, _vp, _vp],
     "vs_search_batch_workspace_bytes": [_vp, _u32, _u64p],
     "vs_search_batch_device": [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp],
     "vs_merge_topk_device": [_vp, _vp, _u32, _u32, _i32, _vp, _vp, _vp, _vp],
@@ -313,6 +314,10 @@ class Store:
         """All arguments are raw device addresses (ints); asynchronous on `stream`."""
         self._ck(lib.vs_search_device(self.handle, d_query, dim, k, d_mask, d_workspace, d_out_keys,
                                       stream))
+
+    def search_device_noalloc(self, d_query, dim, k, d_mask, d_out_keys, stream=0):
+        """vs_search_device on the library's static scratch: no workspace, no allocation."""
+        self._ck(lib.vs_search_device_noalloc(self.handle, d_query, dim, k, d_mask, d_out_keys, stream))
 
 
 # ---- candidate bitmap codecs (host only, no GPU needed) --------------------------------

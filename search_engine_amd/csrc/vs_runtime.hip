@@ -78,6 +78,13 @@ struct Workspace {
     }
 };
 
+// Scratch of the entry point that allocates nothing (vs_search_device_noalloc): the scan's
+// per-workgroup partial lists. One copy per GPU, held until the process ends. Host code never
+// uses this name as an address: vs_init resolves the device address of the current GPU's copy
+// with hipGetSymbolAddress and keeps it in the context.
+constexpr size_t NOALLOC_SCRATCH_BYTES = VS_NOALLOC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+
 constexpr size_t QUERY_BYTES = (size_t)MAX_DIM_VECS * 16 * 2;  // bf16 rows: 8 f32 per vector
 constexpr size_t RESULT_BYTES = (size_t)VS_MAX_K * 8 + 64;
 
@@ -89,6 +96,7 @@ struct vs_ctx {
     std::map<uint16_t, vs_store*> stores;
     std::vector<std::unique_ptr<Workspace>> pool;
     vs::ScanTuning tuning{0, 1};
+    unsigned char* d_scratch = nullptr;  // this GPU's copy of `scratch` (vs_search_device_noalloc)
     // upload staging (guarded by upload_mu)
     std::mutex upload_mu;
     unsigned char* h_stage = nullptr;
@@ -252,11 +260,10 @@ int32_t queue_shared_passes(const vs::SlabView& v, const vs::ScanTuning& t, cons
 }
 
 // One scan of a sealed store under its metric.
-int32_t launch_scan(vs_store* s, const void* d_query, const uint64_t* d_cand, uint32_t k,
-                    uint64_t* d_partial, uint64_t* d_keys, uint32_t* d_ids, float* d_dist,
+int32_t launch_scan(vs_store* s, const vs::ScanTuning& t, const void* d_query, const uint64_t* d_cand,
+                    uint32_t k, uint64_t* d_partial, uint64_t* d_keys, uint32_t* d_ids, float* d_dist,
                     uint32_t* d_n, hipStream_t stream) {
     const vs::SlabView v = s->view();
-    const vs::ScanTuning& t = s->ctx->tuning;
     if (s->metric == VS_HAMMING)
         HIP_TRY(vs::launch_scan_hamming(v, d_query, d_cand, k, d_partial, d_keys, d_ids, d_dist, d_n,
                                         t, stream));
@@ -290,7 +297,7 @@ int32_t run_and_fetch(vs_store* s, Workspace* ws, const float* h_query, uint32_t
     unsigned char* hr = ws->h_pinned + QUERY_BYTES;
     // The merge writes the k results straight into the pinned host block (it is mapped into
     // the device's address space): no copy back, one wait.
-    if (int32_t rc = launch_scan(s, ws->d_query, d_cand, k, ws->d_partial, nullptr,
+    if (int32_t rc = launch_scan(s, t, ws->d_query, d_cand, k, ws->d_partial, nullptr,
                                  reinterpret_cast<uint32_t*>(hr),
                                  reinterpret_cast<float*>(hr + (size_t)VS_MAX_K * 4),
                                  reinterpret_cast<uint32_t*>(hr + (size_t)VS_MAX_K * 8), ws->stream))
@@ -402,7 +409,7 @@ int32_t run_many_and_fetch(vs_store* s, Workspace* ws, const float* h_queries, u
                                                       ws->stream));
         } else {
             for (uint32_t i = 0; i < m; ++i)
-                if (int32_t rc = launch_scan(s, ws->d_batch + i * q_stride, d_cand, k, ws->d_partial, nullptr,
+                if (int32_t rc = launch_scan(s, t, ws->d_batch + i * q_stride, d_cand, k, ws->d_partial, nullptr,
                                              d_ids + (size_t)i * k, d_dist + (size_t)i * k, d_n + i,
                                              ws->stream))
                     return rc;
@@ -482,6 +489,9 @@ extern "C" int32_t vs_init(int32_t device_ordinal, vs_ctx** out) {
     if (const char* v = getenv("VS_SCAN_NT")) ctx->tuning.nt = atoi(v);
     if (const char* v = getenv("VS_SCAN_ROWS")) ctx->tuning.rows_in_flight = atoi(v);
     HIP_TRY(hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
+    // device `device_ordinal` is current: this is its copy of the array
+    HIP_TRY(hipGetSymbolAddress(reinterpret_cast<void**>(&ctx->d_scratch), HIP_SYMBOL(scratch)));
+    if (!ctx->d_scratch) return fail(VS_E_DEVICE, "no device address for the static scratch array");
     *out = ctx.release();
     return VS_OK;
 }
@@ -1014,8 +1024,36 @@ extern "C" int32_t vs_search_device(vs_store* s, const void* d_query, uint32_t d
                     dim);
     }
     if (k == 0 || k > VS_MAX_K) return fail(VS_E_INVALID_ARG, "k = %u out of range", k);
-    return launch_scan(s, d_query, d_mask_words, k, static_cast<uint64_t*>(d_workspace), d_out_keys,
-                       nullptr, nullptr, nullptr, static_cast<hipStream_t>(hip_stream));
+    return launch_scan(s, s->ctx->tuning, d_query, d_mask_words, k, static_cast<uint64_t*>(d_workspace),
+                       d_out_keys, nullptr, nullptr, nullptr, static_cast<hipStream_t>(hip_stream));
+}
+
+// vs_search_device without a workspace argument and without any allocation: the scan's partial
+// lists go to this GPU's static scratch array. The scan overwrites every entry of the partial
+// buffer it later merges (each workgroup writes its k keys, padded with VS_KEY_NONE), so nothing
+// needs clearing between calls; calls that overlap on one GPU would share the array and race.
+extern "C" int32_t vs_search_device_noalloc(vs_store* s, const void* d_query, uint32_t dim, uint32_t k,
+                                            const uint64_t* d_mask_words, uint64_t* d_out_keys,
+                                            void* hip_stream) {
+    if (int32_t rc = check_store(s)) return rc;
+    if (!d_query || !d_out_keys) return fail(VS_E_INVALID_ARG, "null device buffer");
+    if (!s->sealed.load()) return fail(VS_E_NOT_SEALED, "store %u was never sealed", s->index);
+    if (dim != s->dim) {
+        g_dim_expected = s->dim;
+        g_dim_received = dim;
+        return fail(VS_E_DIM_MISMATCH, "invalid vector dimensions: expected %u, received %u", s->dim,
+                    dim);
+    }
+    if (k == 0 || k > VS_MAX_K) return fail(VS_E_INVALID_ARG, "k = %u out of range", k);
+    const vs::ScanTuning t = s->ctx->tuning;  // one snapshot: the size check and the launch agree
+    const uint64_t need = vs::scan_partial_bytes(s->view(), k, t);
+    if (need > NOALLOC_SCRATCH_BYTES)
+        return fail(VS_E_CAPACITY,
+                    "vs_search_device_noalloc: this store and k = %u need %llu bytes of partial lists, the "
+                    "static scratch holds %llu (use vs_search_device with a workspace)",
+                    k, (unsigned long long)need, (unsigned long long)NOALLOC_SCRATCH_BYTES);
+    return launch_scan(s, t, d_query, d_mask_words, k, reinterpret_cast<uint64_t*>(s->ctx->d_scratch),
+                       d_out_keys, nullptr, nullptr, nullptr, static_cast<hipStream_t>(hip_stream));
 }
 
 extern "C" int32_t vs_search_batch_workspace_bytes(vs_store* s, uint32_t k, uint64_t* bytes) {
