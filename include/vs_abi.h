@@ -18,9 +18,16 @@
  *  - document ids are the engine's internal `DocumentId = u32` (src/lib.rs:79);
  *  - results are ordered ascending by (distance, docid), at most `k` of them,
  *    exactly as arroy returns them from nns_by_vector;
- *  - `vs_search*` are thread-safe and re-entrant on a sealed store; upload /
- *    remove / seal need external exclusion (the engine has one LMDB writer);
- *  - a search sees the state of the last `vs_store_seal` (RoTxn snapshot rule).
+ *  - `vs_search*` are thread-safe and re-entrant on a sealed store, also while
+ *    the writer works; upload / remove / reserve / seal are serialised against
+ *    each other by the library (the engine has one LMDB writer anyway);
+ *  - a search sees the items AND the rows of the last `vs_store_seal` that
+ *    completed before it started (the RoTxn snapshot rule): a row uploaded for a
+ *    docid that searches can still see is parked beside the slab and moved in by
+ *    the seal, which for that move alone waits for the searches in flight and
+ *    holds new ones back. Device-API searches (vs_search_device and friends) are
+ *    covered through an event on the stream they were given;
+ *    vs_search_device_noalloc is not (see there).
  *
  * There is no CPU fallback: without a usable HIP device `vs_init` fails with
  * VS_E_DEVICE and no other entry point can be reached.
@@ -107,9 +114,10 @@ int32_t vs_store_create(vs_ctx* ctx, uint16_t store_index, uint32_t dim, int32_t
  * sealed state and the dirty state are kept. milli hands out ever larger internal
  * docids as an index grows (src/update/available_documents_ids.rs); the indexer
  * calls this before `add_item`s beyond the current capacity
- * (src/update/index_documents/typed_chunk.rs:650,691). Needs exclusion from every
- * other call on the store, searches included; masks made for the store before
- * the call are refused afterwards and must be created again. */
+ * (src/update/index_documents/typed_chunk.rs:650,691). Searches may run
+ * meanwhile (they wait while the buffers are swapped); masks made for the store
+ * before the call are refused afterwards and must be created again, and a
+ * device-API caller must size its mask words for the new capacity. */
 int32_t vs_store_reserve(vs_store* s, uint64_t capacity);
 
 /* Looks a store up by index. Replaces Context::vector_reader(index) =
@@ -121,6 +129,7 @@ int32_t vs_store_open(vs_ctx* ctx, uint16_t store_index, vs_store** out);
 /* Adds or overwrites `n` items. `rows` is host memory, row-major f32 [n][dim];
  * the library converts to the store's element type (bf16: round to nearest
  * even; bin1: bit = (x > 0), bit i of a row in word i/64 at position i%64).
+ * Of several rows for one docid the last wins, as with repeated add_item calls.
  * Replaces arroy::Writer::add_item (typed_chunk.rs:650,691). */
 int32_t vs_store_upload(vs_store* s, const uint32_t* docids, const float* rows, uint64_t n);
 
@@ -180,6 +189,10 @@ int32_t vs_search_roaring(vs_store* s, const float* query, uint32_t dim, uint32_
  * store's docid range) and is immutable: any number of threads may search with
  * it. Destroy it before the store. Documents removed or added later need no
  * new mask: a search intersects the mask with the store's sealed state. */
+/* vs_mask_create: docids >= 64 * n_mask_words are not candidates, so
+ * (NULL, 0) makes the EMPTY filter — unlike vs_search, where mask_words == NULL
+ * means "every item"; the mask argument of vs_search_mask expresses that by
+ * being NULL itself. */
 typedef struct vs_mask vs_mask;
 int32_t vs_mask_create(vs_store* s, const uint64_t* mask_words, uint64_t n_mask_words, vs_mask** out);
 int32_t vs_mask_create_roaring(vs_store* s, const uint8_t* roaring_bytes, size_t len, vs_mask** out);
@@ -204,6 +217,20 @@ int32_t vs_search_mask(vs_store* s, const float* query, uint32_t dim, uint32_t k
 int32_t vs_search_batch(vs_store* s, const float* queries, uint32_t n_q, uint32_t dim,
                         uint32_t k, const uint64_t* mask_words, uint64_t n_mask_words,
                         uint32_t* out_ids, float* out_dist, uint32_t* out_n);
+
+/* vs_search_batch with one filter PER QUERY: query i is searched under
+ * masks[i] if `masks` and masks[i] are non-NULL, else under mask_words[i]
+ * (n_mask_words[i] words) if non-NULL, else over every item. Either array may
+ * be NULL as a whole. The reference evaluates one filter per request
+ * (`filtered_universe`, src/search/search.rs:222-228), so a batch of requests
+ * has a universe each. Queries that name the same filter (the same vs_mask or
+ * the same host pointer) share passes exactly as in vs_search_batch; every
+ * other query is scanned under its own mask and reads only its own candidates.
+ * Result i equals vs_search_batch of its group alone. */
+int32_t vs_search_batch_masks(vs_store* s, const float* queries, uint32_t n_q, uint32_t dim,
+                              uint32_t k, const uint64_t* const* mask_words,
+                              const uint64_t* n_mask_words, const vs_mask* const* masks,
+                              uint32_t* out_ids, float* out_dist, uint32_t* out_n);
 
 /* ---- search, device buffers (asynchronous; multi-GPU and benchmark path) -- */
 
@@ -234,7 +261,10 @@ int32_t vs_search_device(vs_store* s, const void* d_query, uint32_t dim, uint32_
  * Limit: (workgroups of the scan, at most 512 by default) * k * 8 bytes must fit,
  * i.e. k <= 256 on a large store; beyond that VS_E_CAPACITY. Every call on one
  * GPU shares the array: calls whose kernels can overlap on that GPU (different
- * streams, or several threads) race; issue them on one stream. */
+ * streams, or several threads) race; issue them on one stream. The call records
+ * no event either (the stream may be under capture), so unlike the other
+ * searches it is not tracked by the snapshot rule: have these searches complete
+ * before a vs_store_seal that replaces or removes items. */
 #define VS_NOALLOC_SCRATCH_BYTES (1u << 20)
 int32_t vs_search_device_noalloc(vs_store* s, const void* d_query, uint32_t dim, uint32_t k,
                                  const uint64_t* d_mask_words, uint64_t* d_out_keys,
@@ -279,6 +309,52 @@ int32_t vs_merge_topk_batch_device(vs_ctx* ctx, const uint64_t* d_keys, uint32_t
                                    uint64_t list_stride, uint32_t n_queries, uint64_t query_stride,
                                    uint32_t k, int32_t metric, uint32_t* d_out_ids,
                                    float* d_out_dist, uint32_t* d_out_n, void* hip_stream);
+
+/* ---- one store sharded over the GPUs of a node --------------------------------- */
+
+/* No counterpart in the reference, which is a single-process library: this is
+ * the multi-GPU form of VectorSort::fill_buffer's loop over stores
+ * (src/search/ranking/vector_sort.rs:73-78) — shards play the role of stores,
+ * their (distance, docid)-ordered lists are merged into the list arroy would
+ * return for one store holding everything. One process per GPU; rank r holds
+ * the docids [r * per, (r + 1) * per), per a multiple of 64, in a store created
+ * with docid_base = r * per. The library owns the RCCL communicator (librccl is
+ * loaded on first use), so the host needs no collective library of its own:
+ *   rank 0:      vs_group_unique_id(id); hand the VS_GROUP_ID_BYTES bytes to
+ *                every rank by whatever channel the host has;
+ *   every rank:  vs_group_create(ctx, rank, world, id, &group)   (collective). */
+typedef struct vs_group vs_group;
+#define VS_GROUP_ID_BYTES 128
+int32_t vs_group_unique_id(uint8_t* out /* VS_GROUP_ID_BYTES */);
+int32_t vs_group_create(vs_ctx* ctx, int32_t rank, int32_t world, const uint8_t* unique_id,
+                        vs_group** out);
+int32_t vs_group_destroy(vs_group* g);
+
+/* Searches `n_q` <= VS_BATCH_MAX_QUERIES queries on every rank's shard and
+ * leaves the GLOBAL top-k of each on every rank: local scans, ONE all-gather of
+ * the shard-local keys (8 * k * n_q bytes per rank) over xGMI, one merge launch.
+ * Collective: every rank of the group calls it with the same n_q, k and flags,
+ * in the same order. Asynchronous on `hip_stream`; a group's calls must be
+ * ordered on the device (one stream, or the caller's own events): its buffers
+ * are reused from call to call, and are grown (an allocation) the first time a
+ * larger n_q * k comes along.
+ *   d_queries:    f32 [n_q][dim] in device memory (VS_BIN1: n_q packed queries
+ *                 of vs_store_row_bytes bytes), the same on every rank
+ *   d_mask_words: this rank's candidate words, aligned to its store as in
+ *                 vs_search_device; NULL = every item
+ *   flags:        0 = one scan per query, every list bit-identical to what
+ *                 vs_search on one store holding all shards returns;
+ *                 VS_SHARDED_SHARE_PASSES = queries share passes over the rows
+ *                 where vs_search_batch_device serves the store (same caveats);
+ *                 VS_SHARDED_ALWAYS_GATHER = run the collective even in a group
+ *                 of one (a rehearsal of the multi-rank path on one GPU)
+ *   outputs:      d_out_ids / d_out_dist [n_q][k], d_out_n [n_q], device memory. */
+#define VS_SHARDED_SHARE_PASSES 1u
+#define VS_SHARDED_ALWAYS_GATHER 2u
+int32_t vs_search_sharded_device(vs_group* g, vs_store* s, const void* d_queries, uint32_t n_q,
+                                 uint32_t dim, uint32_t k, const uint64_t* d_mask_words,
+                                 uint32_t flags, uint32_t* d_out_ids, float* d_out_dist,
+                                 uint32_t* d_out_n, void* hip_stream);
 
 /* ---- candidate bitmaps ---------------------------------------------------- */
 

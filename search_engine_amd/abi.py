@@ -16,6 +16,8 @@ VS_F32, VS_BF16, VS_BIN1 = 0, 1, 2
 VS_ANGULAR, VS_HAMMING, VS_EUCLIDEAN, VS_DOT = 0, 1, 2, 3
 VS_KEY_NONE = 0xFFFFFFFFFFFFFFFF
 VS_MAX_K = 1024
+VS_GROUP_ID_BYTES = 128
+VS_SHARDED_SHARE_PASSES, VS_SHARDED_ALWAYS_GATHER = 1, 2
 
 # VS_AMD_LIB names another build of the same library (measurement variants of the tools)
 LIB_PATH = os.environ.get("VS_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvs_amd.so")
@@ -53,6 +55,8 @@ SIGNATURES = {
     "vs_search": [_vp, _f32p, _u32, _u32, _u64p, _u64, _u32p, _f32p, _u32p],
     "vs_search_roaring": [_vp, _f32p, _u32, _u32, _u8p, _sz, _u32p, _f32p, _u32p],
     "vs_search_batch": [_vp, _f32p, _u32, _u32, _u32, _u64p, _u64, _u32p, _f32p, _u32p],
+    "vs_search_batch_masks": [_vp, _f32p, _u32, _u32, _u32, ctypes.POINTER(_u64p), _u64p,
+                              ctypes.POINTER(_vp), _u32p, _f32p, _u32p],
     "vs_mask_create": [_vp, _u64p, _u64, ctypes.POINTER(_vp)],
     "vs_mask_create_roaring": [_vp, _u8p, _sz, ctypes.POINTER(_vp)],
     "vs_mask_destroy": [_vp],
@@ -64,6 +68,10 @@ SIGNATURES = {
     "vs_search_batch_device": [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp],
     "vs_merge_topk_device": [_vp, _vp, _u32, _u32, _i32, _vp, _vp, _vp, _vp],
     "vs_merge_topk_batch_device": [_vp, _vp, _u32, _u64, _u32, _u64, _u32, _i32, _vp, _vp, _vp, _vp],
+    "vs_group_unique_id": [_u8p],
+    "vs_group_create": [_vp, _i32, _i32, _u8p, ctypes.POINTER(_vp)],
+    "vs_group_destroy": [_vp],
+    "vs_search_sharded_device": [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _u32, _vp, _vp, _vp, _vp],
     "vs_roaring_to_mask": [_u8p, _sz, _u64p, _u64, _u64p],
     "vs_mask_to_roaring": [_u64p, _u64, _u8p, _sz, _szp],
     "vs_cbo_roaring_to_mask": [_u8p, _sz, _u64p, _u64, _u64p],
@@ -173,6 +181,33 @@ class Context:
         _check(lib.vs_merge_topk_batch_device(self.handle, d_keys, n_lists, list_stride, n_queries,
                                               query_stride, k, metric, d_ids, d_dist, d_n, stream),
                self.handle)
+
+
+def group_unique_id():
+    """The bytes rank 0 hands to every rank before Group()."""
+    out = np.zeros(VS_GROUP_ID_BYTES, np.uint8)
+    _check(lib.vs_group_unique_id(_ptr(out, _u8p)))
+    return out.tobytes()
+
+
+class Group:
+    """vs_group: the ranks (one process per GPU) that hold the shards of one logical store."""
+
+    def __init__(self, ctx, rank, world, unique_id):
+        keep, bp = _bytes_ptr(unique_id)
+        assert len(unique_id) == VS_GROUP_ID_BYTES
+        h = _vp()
+        _check(lib.vs_group_create(ctx.handle, rank, world, bp, ctypes.byref(h)), ctx.handle)
+        self.ctx, self.handle, self.rank, self.world = ctx, h, rank, world
+
+    def search_sharded_device(self, store, d_queries, n_q, dim, k, d_mask, flags, d_ids, d_dist, d_n, stream=0):
+        _check(lib.vs_search_sharded_device(self.handle, store.handle, d_queries, n_q, dim, k, d_mask, flags,
+                                            d_ids, d_dist, d_n, stream), self.ctx.handle)
+
+    def destroy(self):
+        if self.handle:
+            lib.vs_group_destroy(self.handle)
+            self.handle = None
 
 
 class Store:
@@ -293,6 +328,33 @@ class Store:
         self._ck(lib.vs_search_batch(self.handle, _ptr(queries, _f32p), n_q, dim, k,
                                      _ptr(mask, _u64p), 0 if mask is None else mask.size,
                                      _ptr(ids, _u32p), _ptr(dist, _f32p), _ptr(cnt, _u32p)))
+        return [(ids[i, : cnt[i]].copy(), dist[i, : cnt[i]].copy()) for i in range(n_q)]
+
+    def search_batch_masks(self, queries, k, masks):
+        """One filter per query: masks[i] is None (every item), dense u64 words, or a handle
+        from create_mask."""
+        queries = np.ascontiguousarray(queries, np.float32)
+        n_q, dim = queries.shape
+        assert len(masks) == n_q
+        words = (_u64p * n_q)()
+        lens = np.zeros(n_q, np.uint64)
+        handles = (_vp * n_q)()
+        keep = []
+        for i, m in enumerate(masks):
+            if m is None:
+                continue
+            if isinstance(m, np.ndarray):
+                keep.append(m if m.dtype == np.uint64 and m.flags.c_contiguous else np.ascontiguousarray(m, np.uint64))
+                words[i] = keep[-1].ctypes.data_as(_u64p)
+                lens[i] = keep[-1].size
+            else:
+                handles[i] = m
+        ids = np.zeros((n_q, max(k, 1)), np.uint32)
+        dist = np.zeros((n_q, max(k, 1)), np.float32)
+        cnt = np.zeros(n_q, np.uint32)
+        self._ck(lib.vs_search_batch_masks(self.handle, _ptr(queries, _f32p), n_q, dim, k, words,
+                                           _ptr(lens, _u64p), handles, _ptr(ids, _u32p), _ptr(dist, _f32p),
+                                           _ptr(cnt, _u32p)))
         return [(ids[i, : cnt[i]].copy(), dist[i, : cnt[i]].copy()) for i in range(n_q)]
 
     def workspace_bytes(self, k):

@@ -35,12 +35,19 @@ struct ScanTuning {
 uint32_t scan_grid_blocks(const SlabView& s, const ScanTuning& t, bool masked);
 // device bytes of the partial-list buffer one scan of this slab writes
 uint64_t scan_partial_bytes(const SlabView& s, uint32_t k, const ScanTuning& t);
+// the same for the largest grid any tuning may ask for: what a caller-provided workspace is
+// sized with, so that a tuning change between sizing and launch cannot overrun it
+constexpr int32_t MAX_TUNED_BLOCKS = 2048;
+uint64_t scan_workspace_bytes(const SlabView& s, uint32_t k);
 
 // Scan of one query over f32 or bf16 rows under s.metric (angular, Euclidean or
 // dot product): writes the per-workgroup top-k lists to `partial` and then the
 // merged ascending top-k keys to `out_keys[k]` (nullable) and, decoded, to
-// out_ids / out_dist / out_n (nullable as a group). `cand` (nullable) is aligned
-// with `present`.
+// out_ids / out_dist / out_n (nullable as a group). With out_keys and out_ids both
+// null only the partial lists are written (rank-major: entry r of workgroup b at
+// partial[r * blocks + b], blocks = scan_grid_blocks(s, t, cand != nullptr)) and the
+// caller merges them, e.g. those of several queries in one launch_merge_batch.
+// `cand` (nullable) is aligned with `present`.
 hipError_t launch_scan_float(const SlabView& s, const float* d_query, const uint64_t* cand,
                                uint32_t k, uint64_t* partial, uint64_t* out_keys,
                                uint32_t* out_ids, float* out_dist, uint32_t* out_n,
@@ -102,10 +109,19 @@ hipError_t launch_scan_batch_bf16(const SlabView& s, const float* d_queries, uin
 hipError_t launch_norms(const SlabView& s, float* norms, uint64_t slot0, uint64_t n,
                         hipStream_t stream);
 
-// Scatter `n` staged f32 rows [n][dim] into the slab at slot docids[i] -
-// docid_base, converting to the slab's element type.
-hipError_t launch_ingest_f32(const SlabView& s, void* rows_out, const float* staged,
-                             const uint32_t* docids, uint64_t n, hipStream_t stream);
+// Scatter `n` staged f32 rows [n][dim], converting to the slab's element type. dest[i] names
+// where row i goes: a slot of `rows_out`; INGEST_SIDE | j = row j of the densely packed side
+// buffer `side_out` (rows that replace an item searches can still see; applied at the next seal);
+// INGEST_SKIP = nowhere (an earlier duplicate of a docid within one upload).
+constexpr uint64_t INGEST_SKIP = 1ull << 63, INGEST_SIDE = 1ull << 62;
+hipError_t launch_ingest_f32(const SlabView& s, void* rows_out, void* side_out, const float* staged,
+                             const uint64_t* dest, uint64_t n, hipStream_t stream);
+// Copies `n` densely packed rows in the slab's element type to the slots d_slots[i].
+hipError_t launch_scatter_rows(const SlabView& s, void* rows_out, const void* staged, const uint64_t* d_slots,
+                               uint64_t n, hipStream_t stream);
+// launch_norms for a list of slots.
+hipError_t launch_norms_slots(const SlabView& s, float* norms, const uint64_t* d_slots, uint64_t n,
+                              hipStream_t stream);
 
 // Merge `n_lists` ascending key lists (entry r of list l at keys[l * list_stride
 // + r * rank_stride]) into the ascending global top-k `out_keys[k]`; when

@@ -1272,6 +1272,35 @@ __global__ __launch_bounds__(256) void norms_kernel(const u32x4* rows, uint32_t 
     }
 }
 
+// the same for a list of slots (rows rewritten in place when a seal applies replaced items)
+template <int ELEM>
+__global__ __launch_bounds__(256) void norms_slots_kernel(const u32x4* rows, uint32_t row_vecs,
+                                                          float* norms, const uint64_t* slots, uint64_t n) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t W = (uint64_t)gridDim.x * 4;
+    for (uint64_t i = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += W) {
+        const uint64_t slot = slots[i];
+        const u32x4* rp = rows + slot * row_vecs;
+        float acc = 0.0f;
+        for (uint32_t idx = lane; idx < row_vecs; idx += 64) acc = self_dot_vec<ELEM>(rp[idx], acc);
+        const float s = wave_sum_f32(acc);
+        if (lane == 0) norms[slot] = sqrtf(s);
+    }
+}
+
+// Copies staged rows (native element type, densely packed) to their slots: one wave per row.
+__global__ __launch_bounds__(256) void scatter_rows_kernel(u32x4* rows_out, uint32_t row_vecs,
+                                                           const u32x4* staged, const uint64_t* slots,
+                                                           uint64_t n) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t W = (uint64_t)gridDim.x * 4;
+    for (uint64_t i = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += W) {
+        const u32x4* src = staged + i * row_vecs;
+        u32x4* dst = rows_out + slots[i] * row_vecs;
+        for (uint32_t idx = lane; idx < row_vecs; idx += 64) dst[idx] = src[idx];
+    }
+}
+
 // ---- ingest ----------------------------------------------------------------------
 
 __device__ __forceinline__ uint32_t f32_to_bf16_rne(float f) {
@@ -1282,15 +1311,20 @@ __device__ __forceinline__ uint32_t f32_to_bf16_rne(float f) {
 }
 
 // one wave per staged row
-__global__ __launch_bounds__(256) void ingest_f32_kernel(unsigned char* rows_out, uint32_t row_vecs,
-                                                         uint32_t dim, uint32_t docid_base,
+// dest[i]: INGEST_SKIP = drop the row; INGEST_SIDE | j = row j of `side_out` (a densely packed
+// side buffer of rows in the slab's element type); otherwise the slab slot.
+__global__ __launch_bounds__(256) void ingest_f32_kernel(unsigned char* rows_out, unsigned char* side_out,
+                                                         uint32_t row_vecs, uint32_t dim,
                                                          int32_t dtype, const float* staged,
-                                                         const uint32_t* docids, uint64_t n) {
+                                                         const uint64_t* dest, uint64_t n) {
     const int lane = threadIdx.x & 63;
     const uint64_t W = (uint64_t)gridDim.x * 4;
     for (uint64_t i = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += W) {
         const float* src = staged + i * dim;
-        unsigned char* dst = rows_out + (uint64_t)(docids[i] - docid_base) * row_vecs * 16;
+        const uint64_t d = dest[i];
+        if (d & INGEST_SKIP) continue;
+        unsigned char* dst = ((d & INGEST_SIDE) ? side_out : rows_out) +
+                             (d & ~(INGEST_SIDE | INGEST_SKIP)) * row_vecs * 16;
         if (dtype == VS_F32) {
             float* o = reinterpret_cast<float*>(dst);
             for (uint32_t e = lane; e < row_vecs * 4; e += 64) o[e] = e < dim ? src[e] : 0.0f;
@@ -1364,6 +1398,12 @@ uint64_t scan_partial_bytes(const SlabView& s, uint32_t k, const ScanTuning& t) 
     return (uint64_t)(a > b ? a : b) * k * sizeof(uint64_t);
 }
 
+uint64_t scan_workspace_bytes(const SlabView& s, uint32_t k) {
+    const uint64_t dflt = scan_partial_bytes(s, k, ScanTuning{0, 1});
+    const uint64_t tuned = (uint64_t)MAX_TUNED_BLOCKS * k * sizeof(uint64_t);
+    return dflt > tuned ? dflt : tuned;
+}
+
 template <int ELEM, int NCH, int U>
 static hipError_t launch_scan_t(const ScanArgs& a, uint32_t blocks, size_t lds, const ScanTuning& t,
                                 hipStream_t stream) {
@@ -1431,6 +1471,7 @@ hipError_t launch_scan_float(const SlabView& s, const float* d_query, const uint
     else
         return hipErrorInvalidValue;
     if (e != hipSuccess) return e;
+    if (!out_keys && !out_ids) return hipSuccess;  // partial lists only: the caller merges
     return launch_merge(partial, blocks, 1, blocks, k, s.metric, out_keys, out_ids, out_dist,
                         out_n, stream);
 }
@@ -1477,6 +1518,7 @@ hipError_t launch_scan_hamming(const SlabView& s, const void* d_query, const uin
     else if (ni <= 8) e = launch_hamming_t<8, 2>(a, blocks, lds, t, stream);
     else return hipErrorInvalidValue;
     if (e != hipSuccess) return e;
+    if (!out_keys && !out_ids) return hipSuccess;  // partial lists only: the caller merges
     return launch_merge(partial, blocks, 1, blocks, k, VS_HAMMING, out_keys, out_ids, out_dist,
                         out_n, stream);
 }
@@ -1716,14 +1758,42 @@ hipError_t launch_norms(const SlabView& s, float* norms, uint64_t slot0, uint64_
     return hipGetLastError();
 }
 
-hipError_t launch_ingest_f32(const SlabView& s, void* rows_out, const float* staged,
-                             const uint32_t* docids, uint64_t n, hipStream_t stream) {
+hipError_t launch_ingest_f32(const SlabView& s, void* rows_out, void* side_out, const float* staged,
+                             const uint64_t* dest, uint64_t n, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     const uint64_t want = (n + 3) / 4;
     const uint32_t blocks = (uint32_t)(want > 4096 ? 4096 : want);
     hipLaunchKernelGGL(ingest_f32_kernel, dim3(blocks), dim3(256), 0, stream,
-                       reinterpret_cast<unsigned char*>(rows_out), s.row_vecs, s.dim, s.docid_base,
-                       s.dtype, staged, docids, n);
+                       reinterpret_cast<unsigned char*>(rows_out), reinterpret_cast<unsigned char*>(side_out),
+                       s.row_vecs, s.dim, s.dtype, staged, dest, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter_rows(const SlabView& s, void* rows_out, const void* staged, const uint64_t* d_slots,
+                               uint64_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const uint64_t want = (n + 3) / 4;
+    const uint32_t blocks = (uint32_t)(want > 4096 ? 4096 : want);
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(blocks), dim3(256), 0, stream,
+                       reinterpret_cast<u32x4*>(rows_out), s.row_vecs, reinterpret_cast<const u32x4*>(staged),
+                       d_slots, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_norms_slots(const SlabView& s, float* norms, const uint64_t* d_slots, uint64_t n,
+                              hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const uint64_t want = (n + 3) / 4;
+    const uint32_t blocks = (uint32_t)(want > 4096 ? 4096 : want);
+    const u32x4* rows = reinterpret_cast<const u32x4*>(s.rows);
+    if (s.dtype == VS_F32)
+        hipLaunchKernelGGL(norms_slots_kernel<VS_F32>, dim3(blocks), dim3(256), 0, stream, rows, s.row_vecs,
+                           norms, d_slots, n);
+    else if (s.dtype == VS_BF16)
+        hipLaunchKernelGGL(norms_slots_kernel<VS_BF16>, dim3(blocks), dim3(256), 0, stream, rows, s.row_vecs,
+                           norms, d_slots, n);
+    else
+        return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

@@ -1,28 +1,38 @@
 // Host side of libvs_amd.so: contexts, stores (row slabs in HBM), the workspace
-// pool that makes searches re-entrant, and the C-ABI entry points declared in
-// include/vs_abi.h. No computation happens here; every distance is produced by
-// the kernels in vs_kernels.hip, and there is no CPU fallback.
+// pool that makes searches re-entrant, the snapshot protocol between searches and
+// the writer, and the C-ABI entry points declared in include/vs_abi.h. No
+// computation happens here; every distance is produced by the kernels in
+// vs_kernels.hip, and there is no CPU fallback.
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
-#include <atomic>
-#include <map>
-#include <memory>
-#include <mutex>
 #include <string>
-#include <vector>
 
-#include "../../include/vs_abi.h"
-#include "vs_kernels.h"
+#include "vs_internal.h"
 #include "vs_roaring.h"
+
+using vsrt::fail;
+using vsrt::Snapshot;
+using vsrt::Workspace;
 
 namespace {
 
 thread_local std::string g_err;
 thread_local uint32_t g_dim_expected = 0, g_dim_received = 0;
+
+// Scratch of the entry point that allocates nothing (vs_search_device_noalloc): the scan's
+// per-workgroup partial lists. One copy per GPU, held until the process ends. Host code never
+// uses this name as an address: vs_init resolves the device address of the current GPU's copy
+// with hipGetSymbolAddress and keeps it in the context.
+constexpr size_t NOALLOC_SCRATCH_BYTES = VS_NOALLOC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+
+}  // namespace
+
+namespace vsrt {
 
 int32_t fail(int32_t code, const char* fmt, ...) {
     char buf[512];
@@ -34,118 +44,21 @@ int32_t fail(int32_t code, const char* fmt, ...) {
     return code;
 }
 
-#define HIP_TRY(expr)                                                                      \
-    do {                                                                                   \
-        const hipError_t e_ = (expr);                                                      \
-        if (e_ != hipSuccess)                                                              \
-            return fail(e_ == hipErrorOutOfMemory ? VS_E_OOM : VS_E_DEVICE, "%s failed: %s", \
-                        #expr, hipGetErrorString(e_));                                     \
-    } while (0)
+void set_dim_mismatch(uint32_t expected, uint32_t received) {
+    g_dim_expected = expected;
+    g_dim_received = received;
+}
 
-constexpr uint32_t MAX_DIM_VECS = 16 * 64;  // row vectors the angular scan kernels are built for
-constexpr uint32_t MAX_BIN_VECS = 32;       // and the Hamming scan (4096 bits)
-constexpr size_t STAGE_BYTES = 32u << 20;
-
-// Everything one in-flight host-buffer search needs; handed out by the pool so
-// that concurrent vs_search calls never share a stream or a buffer.
-struct Workspace {
-    hipStream_t stream = nullptr;
-    float* d_query = nullptr;
-    uint64_t* d_mask = nullptr;
-    size_t mask_words = 0;
-    uint64_t* d_partial = nullptr;
-    size_t partial_bytes = 0;
-    uint64_t* d_keys = nullptr;  // VS_MAX_K keys, ids, distances and the count, one allocation
-    uint32_t* d_ids = nullptr;
-    float* d_dist = nullptr;
-    uint32_t* d_n = nullptr;
-    uint8_t* d_blob = nullptr;
-    size_t blob_bytes = 0;
-    unsigned char* d_batch = nullptr;  // batched path: queries, kernel workspace, results
-    size_t batch_bytes = 0;
-    unsigned char* h_pinned = nullptr;  // query, then results
-    size_t pinned_bytes = 0;
-
-    ~Workspace() {
-        if (d_query) (void)hipFree(d_query);
-        if (d_mask) (void)hipFree(d_mask);
-        if (d_partial) (void)hipFree(d_partial);
-        if (d_keys) (void)hipFree(d_keys);
-        if (d_blob) (void)hipFree(d_blob);
-        if (d_batch) (void)hipFree(d_batch);
-        if (h_pinned) (void)hipHostFree(h_pinned);
-        if (stream) (void)hipStreamDestroy(stream);
-    }
-};
-
-// Scratch of the entry point that allocates nothing (vs_search_device_noalloc): the scan's
-// per-workgroup partial lists. One copy per GPU, held until the process ends. Host code never
-// uses this name as an address: vs_init resolves the device address of the current GPU's copy
-// with hipGetSymbolAddress and keeps it in the context.
-constexpr size_t NOALLOC_SCRATCH_BYTES = VS_NOALLOC_SCRATCH_BYTES;
-static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
-
-constexpr size_t QUERY_BYTES = (size_t)MAX_DIM_VECS * 16 * 2;  // bf16 rows: 8 f32 per vector
-constexpr size_t RESULT_BYTES = (size_t)VS_MAX_K * 8 + 64;
-
-}  // namespace
-
-struct vs_ctx {
-    int device = 0;
-    std::mutex mu;  // stores map, pool, staging
-    std::map<uint16_t, vs_store*> stores;
-    std::vector<std::unique_ptr<Workspace>> pool;
-    vs::ScanTuning tuning{0, 1};
-    unsigned char* d_scratch = nullptr;  // this GPU's copy of `scratch` (vs_search_device_noalloc)
-    // upload staging (guarded by upload_mu)
-    std::mutex upload_mu;
-    unsigned char* h_stage = nullptr;
-    unsigned char* d_stage = nullptr;
-    hipStream_t upload_stream = nullptr;
-};
-
-struct vs_mask {
-    vs_store* store;
-    uint64_t* d_words;  // store->n_slots / 64 words, aligned with the store
-    uint64_t n_slots;   // of the store when the mask was made (vs_store_reserve outdates it)
-};
-
-struct vs_store {
-    vs_ctx* ctx = nullptr;
-    uint16_t index = 0;
-    uint32_t dim = 0;
-    int32_t dtype = VS_F32, metric = VS_ANGULAR;
-    uint32_t docid_base = 0;
-    uint64_t capacity = 0, n_slots = 0;
-    uint32_t row_vecs = 0;
-    void* d_rows = nullptr;
-    float* d_norms = nullptr;
-    uint64_t* d_present[2] = {nullptr, nullptr};  // searches read [active]; seal fills the other
-    std::atomic<int> active{0};
-    std::vector<uint64_t> h_present;  // writer's view, published by seal
-    uint64_t n_items = 0;             // of h_present
-    std::atomic<uint64_t> sealed_items{0};
-    uint64_t dirty_lo = 0, dirty_hi = 0;  // slot range uploaded since the last seal
-    bool dirty = false;
-    std::atomic<bool> sealed{false};
-
-    vs::SlabView view() const {
-        vs::SlabView v;
-        v.rows = d_rows;
-        v.norms = d_norms;
-        v.present = d_present[active.load(std::memory_order_acquire)];
-        v.n_slots = n_slots;
-        v.row_vecs = row_vecs;
-        v.dim = dim;
-        v.docid_base = docid_base;
-        v.dtype = dtype;
-        v.metric = metric;
-        return v;
-    }
-    uint64_t row_bytes() const { return (uint64_t)row_vecs * 16; }
-};
-
-namespace {
+Workspace::~Workspace() {
+    if (d_query) (void)hipFree(d_query);
+    if (d_mask) (void)hipFree(d_mask);
+    if (d_partial) (void)hipFree(d_partial);
+    if (d_keys) (void)hipFree(d_keys);
+    if (d_blob) (void)hipFree(d_blob);
+    if (d_batch) (void)hipFree(d_batch);
+    if (h_pinned) (void)hipHostFree(h_pinned);
+    if (stream) (void)hipStreamDestroy(stream);
+}
 
 int32_t ws_acquire(vs_ctx* ctx, std::unique_ptr<Workspace>* out) {
     {
@@ -172,25 +85,21 @@ int32_t ws_acquire(vs_ctx* ctx, std::unique_ptr<Workspace>* out) {
 }
 
 void ws_release(vs_ctx* ctx, std::unique_ptr<Workspace> ws) {
-    std::lock_guard<std::mutex> g(ctx->mu);
-    ctx->pool.push_back(std::move(ws));
+    std::unique_lock<std::mutex> g(ctx->mu);
+    if (ctx->pool.size() < POOL_KEEP) {
+        ctx->pool.push_back(std::move(ws));
+        return;
+    }
+    g.unlock();
+    ws.reset();  // beyond what the pool keeps: released outside the lock
 }
 
-template <typename T>
-int32_t grow(T** p, size_t* have, size_t want) {
-    if (*have >= want) return VS_OK;
-    if (*p) (void)hipFree(*p);
-    *p = nullptr;
-    *have = 0;
-    HIP_TRY(hipMalloc(p, want));
-    *have = want;
-    return VS_OK;
-}
-
-uint32_t vecs_for(uint32_t dim, int32_t dtype) {
-    if (dtype == VS_F32) return (dim + 3) / 4;
-    if (dtype == VS_BF16) return (dim + 7) / 8;
-    return (dim + 127) / 128;
+vs::ScanTuning tuning_of(const vs_ctx* ctx) {
+    vs::ScanTuning t{0, 1};
+    t.blocks = ctx->tune_blocks.load(std::memory_order_relaxed);
+    t.nt = ctx->tune_nt.load(std::memory_order_relaxed);
+    t.rows_in_flight = ctx->tune_rows.load(std::memory_order_relaxed);
+    return t;
 }
 
 int32_t check_store(vs_store* s) {
@@ -199,7 +108,107 @@ int32_t check_store(vs_store* s) {
     return VS_OK;
 }
 
-// Common front half of the host-buffer searches: argument checks and the query upload.
+void snapshot_begin(vs_store* s, Snapshot* out) {
+    std::unique_lock<std::mutex> lk(s->snap_mu);
+    s->snap_cv.wait(lk, [&] { return !s->writer_blocks; });
+    out->buf = s->active;
+    ++s->readers[out->buf];
+    out->v = s->view(out->buf);
+}
+
+void snapshot_end(vs_store* s, Snapshot* snap) {
+    if (snap->buf < 0) return;
+    std::lock_guard<std::mutex> lk(s->snap_mu);
+    if (--s->readers[snap->buf] == 0) s->snap_cv.notify_all();
+    snap->buf = -1;
+}
+
+int32_t snapshot_end_async(vs_store* s, Snapshot* snap, hipStream_t stream, bool track) {
+    if (snap->buf < 0) return VS_OK;
+    int32_t rc = VS_OK;
+    std::lock_guard<std::mutex> lk(s->snap_mu);
+    if (track) {
+        // one event per (buffer, caller stream), re-recorded by every search: waiting for it
+        // waits for the stream's latest search on this buffer
+        hipEvent_t& ev = s->stream_events[snap->buf][stream];
+        hipError_t e = hipSuccess;
+        if (!ev) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(ev, stream);
+        if (e != hipSuccess) rc = fail(VS_E_DEVICE, "cannot record the search's event: %s", hipGetErrorString(e));
+    }
+    if (--s->readers[snap->buf] == 0) s->snap_cv.notify_all();
+    snap->buf = -1;
+    return rc;
+}
+
+int32_t check_device_search(vs_store* s, uint32_t dim, uint32_t k) {
+    if (!s->sealed.load()) return fail(VS_E_NOT_SEALED, "store %u was never sealed", s->index);
+    if (dim != s->dim) {
+        set_dim_mismatch(s->dim, dim);
+        return fail(VS_E_DIM_MISMATCH, "invalid vector dimensions: expected %u, received %u", s->dim, dim);
+    }
+    if (k == 0 || k > VS_MAX_K) return fail(VS_E_INVALID_ARG, "k = %u out of range", k);
+    return VS_OK;
+}
+
+int32_t launch_scan(const vs::SlabView& v, const vs::ScanTuning& t, const void* d_query, const uint64_t* d_cand,
+                    uint32_t k, uint64_t* d_partial, uint64_t* d_keys, uint32_t* d_ids, float* d_dist,
+                    uint32_t* d_n, hipStream_t stream) {
+    if (v.metric == VS_HAMMING)
+        HIP_TRY(vs::launch_scan_hamming(v, d_query, d_cand, k, d_partial, d_keys, d_ids, d_dist, d_n, t, stream));
+    else
+        HIP_TRY(vs::launch_scan_float(v, static_cast<const float*>(d_query), d_cand, k, d_partial, d_keys, d_ids,
+                                      d_dist, d_n, t, stream));
+    return VS_OK;
+}
+
+}  // namespace vsrt
+
+namespace {
+
+using namespace vsrt;
+
+// Writer side: waits until no search registered on present buffer `buf` is left: the host-side
+// count drains, then the events of device-API searches complete. Called with snap_mu held through
+// `lk`; the lock is dropped while events are waited for (no new search can register on an inactive
+// buffer, nor on any buffer while writer_blocks is set).
+int32_t wait_readers(vs_store* s, int buf, std::unique_lock<std::mutex>& lk) {
+    s->snap_cv.wait(lk, [&] { return s->readers[buf] == 0; });
+    std::vector<hipEvent_t> evs;
+    for (auto& kv : s->stream_events[buf]) evs.push_back(kv.second);
+    lk.unlock();
+    hipError_t bad = hipSuccess;
+    for (hipEvent_t ev : evs) {
+        const hipError_t e = hipEventSynchronize(ev);
+        if (e != hipSuccess) bad = e;
+    }
+    lk.lock();
+    if (bad != hipSuccess) return fail(VS_E_DEVICE, "waiting for searches in flight failed: %s", hipGetErrorString(bad));
+    return VS_OK;
+}
+
+// Stops new searches and waits for every search in flight on either buffer. The caller clears
+// writer_blocks (resume) when the store may be read again.
+int32_t quiesce(vs_store* s) {
+    std::unique_lock<std::mutex> lk(s->snap_mu);
+    s->writer_blocks = true;
+    if (int32_t rc = wait_readers(s, 0, lk)) return rc;
+    return wait_readers(s, 1, lk);
+}
+
+void resume(vs_store* s) {
+    std::lock_guard<std::mutex> lk(s->snap_mu);
+    s->writer_blocks = false;
+    s->snap_cv.notify_all();
+}
+
+uint32_t vecs_for(uint32_t dim, int32_t dtype) {
+    if (dtype == VS_F32) return (dim + 3) / 4;
+    if (dtype == VS_BF16) return (dim + 7) / 8;
+    return (dim + 127) / 128;
+}
+
+// Common front half of the host-buffer searches: argument checks.
 int32_t begin_search(vs_store* s, const float* query, uint32_t dim, uint32_t k, uint32_t* out_ids,
                      float* out_dist, uint32_t* out_n) {
     if (int32_t rc = check_store(s)) return rc;
@@ -207,8 +216,7 @@ int32_t begin_search(vs_store* s, const float* query, uint32_t dim, uint32_t k, 
         return fail(VS_E_INVALID_ARG, "null query or output buffer");
     if (!s->sealed.load()) return fail(VS_E_NOT_SEALED, "store %u was never sealed", s->index);
     if (dim != s->dim) {
-        g_dim_expected = s->dim;
-        g_dim_received = dim;
+        set_dim_mismatch(s->dim, dim);
         return fail(VS_E_DIM_MISMATCH, "invalid vector dimensions: expected %u, received %u", s->dim,
                     dim);
     }
@@ -228,8 +236,9 @@ bool on_matrix_cores(const vs_store* s, uint32_t k) {
 // The caller has checked shared_pass_serves().
 bool shared_pass_serves(const vs::SlabView& v, uint32_t k) { return vs::scan_multi_serves(v, k); }
 constexpr uint32_t MQ32_MIN_QUERIES = 17;
-uint64_t shared_pass_partial_bytes(const vs::SlabView& v, uint32_t k, const vs::ScanTuning& t) {
-    const uint64_t a = vs::scan_partial_bytes(v, k, t) * vs::scan_multi_queries(v);
+// sized for the largest grid a tuning may ask for (the workspace may outlive a tuning change)
+uint64_t shared_pass_partial_bytes(const vs::SlabView& v, uint32_t k) {
+    const uint64_t a = vs::scan_workspace_bytes(v, k) * vs::scan_multi_queries(v);
     const uint64_t b = vs::scan_mq32_serves(v, k) ? vs::scan_mq32_partial_bytes(v, k) : 0;
     return a > b ? a : b;
 }
@@ -259,26 +268,11 @@ int32_t queue_shared_passes(const vs::SlabView& v, const vs::ScanTuning& t, cons
     return VS_OK;
 }
 
-// One scan of a sealed store under its metric.
-int32_t launch_scan(vs_store* s, const vs::ScanTuning& t, const void* d_query, const uint64_t* d_cand,
-                    uint32_t k, uint64_t* d_partial, uint64_t* d_keys, uint32_t* d_ids, float* d_dist,
-                    uint32_t* d_n, hipStream_t stream) {
-    const vs::SlabView v = s->view();
-    if (s->metric == VS_HAMMING)
-        HIP_TRY(vs::launch_scan_hamming(v, d_query, d_cand, k, d_partial, d_keys, d_ids, d_dist, d_n,
-                                        t, stream));
-    else
-        HIP_TRY(vs::launch_scan_float(v, static_cast<const float*>(d_query), d_cand, k, d_partial,
-                                        d_keys, d_ids, d_dist, d_n, t, stream));
-    return VS_OK;
-}
-
 // Runs one query whose candidate mask (aligned to the store, or null) is already
 // on the device, and copies the decoded result back.
-int32_t run_and_fetch(vs_store* s, Workspace* ws, const float* h_query, uint32_t k,
+int32_t run_and_fetch(vs_store* s, const vs::SlabView& v, Workspace* ws, const float* h_query, uint32_t k,
                       const uint64_t* d_cand, uint32_t* out_ids, float* out_dist, uint32_t* out_n) {
-    const vs::SlabView v = s->view();
-    const vs::ScanTuning& t = s->ctx->tuning;
+    const vs::ScanTuning t = tuning_of(s->ctx);
     if (int32_t rc = grow(&ws->d_partial, &ws->partial_bytes, (size_t)vs::scan_partial_bytes(v, k, t)))
         return rc;
     size_t query_bytes;
@@ -297,7 +291,7 @@ int32_t run_and_fetch(vs_store* s, Workspace* ws, const float* h_query, uint32_t
     unsigned char* hr = ws->h_pinned + QUERY_BYTES;
     // The merge writes the k results straight into the pinned host block (it is mapped into
     // the device's address space): no copy back, one wait.
-    if (int32_t rc = launch_scan(s, t, ws->d_query, d_cand, k, ws->d_partial, nullptr,
+    if (int32_t rc = launch_scan(v, t, ws->d_query, d_cand, k, ws->d_partial, nullptr,
                                  reinterpret_cast<uint32_t*>(hr),
                                  reinterpret_cast<float*>(hr + (size_t)VS_MAX_K * 4),
                                  reinterpret_cast<uint32_t*>(hr + (size_t)VS_MAX_K * 8), ws->stream))
@@ -314,10 +308,9 @@ int32_t run_and_fetch(vs_store* s, Workspace* ws, const float* h_query, uint32_t
 
 // Batched matrix-core path for bf16 stores: chunks of up to 256 queries, each one
 // pass over the rows.
-int32_t run_batch_and_fetch(vs_store* s, Workspace* ws, const float* h_queries, uint32_t n_q,
-                            uint32_t k, const uint64_t* d_cand, uint32_t* out_ids, float* out_dist,
-                            uint32_t* out_n) {
-    const vs::SlabView v = s->view();
+int32_t run_batch_and_fetch(vs_store* s, const vs::SlabView& v, Workspace* ws, const float* h_queries,
+                            uint32_t n_q, uint32_t k, const uint64_t* d_cand, uint32_t* out_ids,
+                            float* out_dist, uint32_t* out_n) {
     const size_t chunk_q = VS_BATCH_MAX_QUERIES;
     const size_t q_bytes = chunk_q * s->dim * 4;
     const size_t res_bytes = chunk_q * k * 8 + chunk_q * 4;  // ids, distances, counts
@@ -358,17 +351,17 @@ int32_t run_batch_and_fetch(vs_store* s, Workspace* ws, const float* h_queries, 
 // scan serves the store, else one scan each; the launches of a chunk are queued back to back on the
 // workspace's stream, with ONE upload of the queries, ONE download of the results and ONE wait
 // per chunk.
-int32_t run_many_and_fetch(vs_store* s, Workspace* ws, const float* h_queries, uint32_t n_q, uint32_t k,
-                           const uint64_t* d_cand, uint32_t* out_ids, float* out_dist, uint32_t* out_n) {
-    const vs::SlabView v = s->view();
-    const vs::ScanTuning& t = s->ctx->tuning;
+int32_t run_many_and_fetch(vs_store* s, const vs::SlabView& v, Workspace* ws, const float* h_queries,
+                           uint32_t n_q, uint32_t k, const uint64_t* d_cand, uint32_t* out_ids,
+                           float* out_dist, uint32_t* out_n) {
+    const vs::ScanTuning t = tuning_of(s->ctx);
     // several queries share every pass over the rows where one of the multi-query scans serves the store
     const bool shared = shared_pass_serves(v, k);
     const bool shared_bits = vs::scan_hamming_multi_serves(v, k);  // binary rows: four queries per pass
     if (int32_t rc = grow(&ws->d_partial, &ws->partial_bytes,
-                          shared        ? (size_t)shared_pass_partial_bytes(v, k, t)
-                          : shared_bits ? (size_t)vs::scan_partial_bytes(v, k, t) * 4
-                                        : (size_t)vs::scan_partial_bytes(v, k, t)))
+                          shared        ? (size_t)shared_pass_partial_bytes(v, k)
+                          : shared_bits ? (size_t)vs::scan_workspace_bytes(v, k) * 4
+                                        : (size_t)vs::scan_workspace_bytes(v, k)))
         return rc;
     const size_t chunk_q = 64;
     const bool bin = s->dtype == VS_BIN1;
@@ -409,7 +402,7 @@ int32_t run_many_and_fetch(vs_store* s, Workspace* ws, const float* h_queries, u
                                                       ws->stream));
         } else {
             for (uint32_t i = 0; i < m; ++i)
-                if (int32_t rc = launch_scan(s, t, ws->d_batch + i * q_stride, d_cand, k, ws->d_partial, nullptr,
+                if (int32_t rc = launch_scan(v, t, ws->d_batch + i * q_stride, d_cand, k, ws->d_partial, nullptr,
                                              d_ids + (size_t)i * k, d_dist + (size_t)i * k, d_n + i,
                                              ws->stream))
                     return rc;
@@ -463,6 +456,22 @@ int32_t expand_roaring(vs_store* s, Workspace* ws, const uint8_t* roaring_bytes,
     return VS_OK;
 }
 
+// A host-buffer search from begin to end: workspace, snapshot, body, release. `body` gets the
+// workspace and the registered view and has waited for the workspace's stream when it returns
+// VS_OK.
+template <typename F>
+int32_t with_snapshot(vs_store* s, F&& body) {
+    std::unique_ptr<Workspace> ws;
+    if (int32_t rc = ws_acquire(s->ctx, &ws)) return rc;
+    Snapshot snap;
+    snapshot_begin(s, &snap);
+    const int32_t rc = body(ws.get(), snap.v);
+    if (rc != VS_OK) (void)hipStreamSynchronize(ws->stream);  // nothing of a failed call stays in flight
+    snapshot_end(s, &snap);
+    ws_release(s->ctx, std::move(ws));
+    return rc;
+}
+
 }  // namespace
 
 // ---- context -------------------------------------------------------------------
@@ -485,10 +494,17 @@ extern "C" int32_t vs_init(int32_t device_ordinal, vs_ctx** out) {
                     device_ordinal, prop.gcnArchName);
     std::unique_ptr<vs_ctx> ctx(new vs_ctx());
     ctx->device = device_ordinal;
-    if (const char* v = getenv("VS_SCAN_BLOCKS")) ctx->tuning.blocks = atoi(v);
-    if (const char* v = getenv("VS_SCAN_NT")) ctx->tuning.nt = atoi(v);
-    if (const char* v = getenv("VS_SCAN_ROWS")) ctx->tuning.rows_in_flight = atoi(v);
+    auto env_int = [](const char* name, int32_t lo, int32_t hi, std::atomic<int32_t>* dst) {
+        if (const char* v = getenv(name)) {
+            const int32_t x = atoi(v);
+            if (x >= lo && x <= hi) dst->store(x);
+        }
+    };
+    env_int("VS_SCAN_BLOCKS", 0, vs::MAX_TUNED_BLOCKS, &ctx->tune_blocks);
+    env_int("VS_SCAN_NT", 0, 1, &ctx->tune_nt);
+    env_int("VS_SCAN_ROWS", 0, 8, &ctx->tune_rows);
     HIP_TRY(hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
+    HIP_TRY(hipHostMalloc(&ctx->h_small, 64 << 10, hipHostMallocDefault));
     // device `device_ordinal` is current: this is its copy of the array
     HIP_TRY(hipGetSymbolAddress(reinterpret_cast<void**>(&ctx->d_scratch), HIP_SYMBOL(scratch)));
     if (!ctx->d_scratch) return fail(VS_E_DEVICE, "no device address for the static scratch array");
@@ -508,6 +524,7 @@ extern "C" int32_t vs_shutdown(vs_ctx* ctx) {
     for (vs_store* s : stores) vs_store_destroy(s);
     ctx->pool.clear();
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    if (ctx->h_small) (void)hipHostFree(ctx->h_small);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->upload_stream) (void)hipStreamDestroy(ctx->upload_stream);
     delete ctx;
@@ -528,9 +545,10 @@ extern "C" int32_t vs_last_dim_mismatch(vs_ctx*, uint32_t* expected, uint32_t* r
 
 extern "C" int32_t vs_set_scan_tuning(vs_ctx* ctx, int32_t blocks, int32_t nt) {
     if (!ctx) return fail(VS_E_INVALID_ARG, "null context");
-    if (blocks < 0 || blocks > 65535) return fail(VS_E_INVALID_ARG, "bad tuning values");
-    ctx->tuning.blocks = blocks;
-    ctx->tuning.nt = nt ? 1 : 0;
+    if (blocks < 0 || blocks > vs::MAX_TUNED_BLOCKS)
+        return fail(VS_E_INVALID_ARG, "blocks = %d out of range (0 .. %d)", blocks, vs::MAX_TUNED_BLOCKS);
+    ctx->tune_blocks.store(blocks);
+    ctx->tune_nt.store(nt ? 1 : 0);
     return VS_OK;
 }
 
@@ -574,19 +592,31 @@ extern "C" int32_t vs_store_create(vs_ctx* ctx, uint16_t store_index, uint32_t d
     s->n_slots = (capacity + 63) / 64 * 64;
     s->row_vecs = row_vecs;
     const size_t n_words = s->n_slots / 64;
-    // 192 zeroed rows of padding: the batched scan reads whole 256-row tiles
-    HIP_TRY(hipMalloc(&s->d_rows, (size_t)(s->n_slots + vs::SLAB_PAD_ROWS) * s->row_bytes()));
-    HIP_TRY(hipMemset(static_cast<unsigned char*>(s->d_rows) + (size_t)s->n_slots * s->row_bytes(), 0,
-                      (size_t)vs::SLAB_PAD_ROWS * s->row_bytes()));
-    HIP_TRY(hipMalloc(&s->d_present[0], n_words * 8));
-    HIP_TRY(hipMalloc(&s->d_present[1], n_words * 8));
-    HIP_TRY(hipMemset(s->d_present[0], 0, n_words * 8));
-    HIP_TRY(hipMemset(s->d_present[1], 0, n_words * 8));
-    if (metric == VS_ANGULAR) {
-        HIP_TRY(hipMalloc(&s->d_norms, (size_t)s->n_slots * 4));
-        HIP_TRY(hipMemset(s->d_norms, 0, (size_t)s->n_slots * 4));
+    auto body = [&]() -> int32_t {
+        // 192 zeroed rows of padding: the batched scan reads whole 256-row tiles
+        HIP_TRY(hipMalloc(&s->d_rows, (size_t)(s->n_slots + vs::SLAB_PAD_ROWS) * s->row_bytes()));
+        HIP_TRY(hipMemset(static_cast<unsigned char*>(s->d_rows) + (size_t)s->n_slots * s->row_bytes(), 0,
+                          (size_t)vs::SLAB_PAD_ROWS * s->row_bytes()));
+        HIP_TRY(hipMalloc(&s->d_present[0], n_words * 8));
+        HIP_TRY(hipMalloc(&s->d_present[1], n_words * 8));
+        HIP_TRY(hipMemset(s->d_present[0], 0, n_words * 8));
+        HIP_TRY(hipMemset(s->d_present[1], 0, n_words * 8));
+        if (metric == VS_ANGULAR) {
+            HIP_TRY(hipMalloc(&s->d_norms, (size_t)s->n_slots * 4));
+            HIP_TRY(hipMemset(s->d_norms, 0, (size_t)s->n_slots * 4));
+        }
+        return VS_OK;
+    };
+    if (int32_t rc = body()) {
+        if (s->d_rows) (void)hipFree(s->d_rows);
+        if (s->d_norms) (void)hipFree(s->d_norms);
+        for (int i = 0; i < 2; ++i)
+            if (s->d_present[i]) (void)hipFree(s->d_present[i]);
+        return rc;
     }
     s->h_present.assign(n_words, 0);
+    s->h_sealed.assign(n_words, 0);
+    s->h_visible.assign(n_words, 0);
     {
         std::lock_guard<std::mutex> g(ctx->mu);
         ctx->stores[store_index] = s.get();
@@ -597,55 +627,63 @@ extern "C" int32_t vs_store_create(vs_ctx* ctx, uint16_t store_index, uint32_t d
 
 extern "C" int32_t vs_store_reserve(vs_store* s, uint64_t capacity) {
     if (int32_t rc = check_store(s)) return rc;
+    std::lock_guard<std::mutex> g(s->ctx->upload_mu);
     if (capacity <= s->capacity) return VS_OK;
     if ((uint64_t)s->docid_base + capacity > (1ull << 32))
         return fail(VS_E_INVALID_ARG, "docid range [%u, %u + %llu) does not fit u32 docids", s->docid_base,
                     s->docid_base, (unsigned long long)capacity);
-    HIP_TRY(hipSetDevice(s->ctx->device));
-    HIP_TRY(hipDeviceSynchronize());  // nothing of this store is in flight (the caller's side of the contract)
+    for (auto& kv : s->upload_events) HIP_TRY(hipEventSynchronize(kv.second));
     const uint64_t old_slots = s->n_slots, new_slots = (capacity + 63) / 64 * 64;
     const size_t rb = s->row_bytes(), old_words = old_slots / 64, new_words = new_slots / 64;
     void* rows = nullptr;
     float* norms = nullptr;
     uint64_t* present[2] = {nullptr, nullptr};
+    hipStream_t st = s->ctx->upload_stream;
+    // the copies read rows and bitmaps no writer is changing (this thread is the writer);
+    // searches go on until the pointers are swapped
     auto body = [&]() -> int32_t {
         HIP_TRY(hipMalloc(&rows, (size_t)(new_slots + vs::SLAB_PAD_ROWS) * rb));
-        HIP_TRY(hipMemcpy(rows, s->d_rows, (size_t)old_slots * rb, hipMemcpyDeviceToDevice));
-        HIP_TRY(hipMemset(static_cast<unsigned char*>(rows) + (size_t)old_slots * rb, 0,
-                          (size_t)(new_slots - old_slots + vs::SLAB_PAD_ROWS) * rb));
+        HIP_TRY(hipMemcpyAsync(rows, s->d_rows, (size_t)old_slots * rb, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemsetAsync(static_cast<unsigned char*>(rows) + (size_t)old_slots * rb, 0,
+                               (size_t)(new_slots - old_slots + vs::SLAB_PAD_ROWS) * rb, st));
         for (int i = 0; i < 2; ++i) {
             HIP_TRY(hipMalloc(&present[i], new_words * 8));
-            HIP_TRY(hipMemcpy(present[i], s->d_present[i], old_words * 8, hipMemcpyDeviceToDevice));
-            HIP_TRY(hipMemset(present[i] + old_words, 0, (new_words - old_words) * 8));
+            HIP_TRY(hipMemcpyAsync(present[i], s->d_present[i], old_words * 8, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemsetAsync(present[i] + old_words, 0, (new_words - old_words) * 8, st));
         }
         if (s->d_norms) {
             HIP_TRY(hipMalloc(&norms, (size_t)new_slots * 4));
-            HIP_TRY(hipMemcpy(norms, s->d_norms, (size_t)old_slots * 4, hipMemcpyDeviceToDevice));
-            HIP_TRY(hipMemset(norms + old_slots, 0, (size_t)(new_slots - old_slots) * 4));
+            HIP_TRY(hipMemcpyAsync(norms, s->d_norms, (size_t)old_slots * 4, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemsetAsync(norms + old_slots, 0, (size_t)(new_slots - old_slots) * 4, st));
         }
-        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipStreamSynchronize(st));
         return VS_OK;
     };
-    if (int32_t rc = body()) {
+    int32_t rc = body();
+    if (rc == VS_OK) rc = quiesce(s);  // searches in flight still read the old buffers
+    if (rc != VS_OK) {
+        resume(s);
         if (rows) (void)hipFree(rows);
         if (norms) (void)hipFree(norms);
         for (int i = 0; i < 2; ++i)
             if (present[i]) (void)hipFree(present[i]);
         return rc;
     }
-    (void)hipFree(s->d_rows);
+    void* old_rows = s->d_rows;
+    float* old_norms = s->d_norms;
+    uint64_t* old_present[2] = {s->d_present[0], s->d_present[1]};
     s->d_rows = rows;
-    if (s->d_norms) {
-        (void)hipFree(s->d_norms);
-        s->d_norms = norms;
-    }
-    for (int i = 0; i < 2; ++i) {
-        (void)hipFree(s->d_present[i]);
-        s->d_present[i] = present[i];
-    }
+    if (s->d_norms) s->d_norms = norms;
+    for (int i = 0; i < 2; ++i) s->d_present[i] = present[i];
     s->h_present.resize(new_words, 0);
+    s->h_sealed.resize(new_words, 0);
+    s->h_visible.resize(new_words, 0);
     s->capacity = capacity;
     s->n_slots = new_slots;
+    resume(s);
+    (void)hipFree(old_rows);
+    if (old_norms) (void)hipFree(old_norms);
+    for (int i = 0; i < 2; ++i) (void)hipFree(old_present[i]);
     return VS_OK;
 }
 
@@ -663,20 +701,32 @@ extern "C" int32_t vs_store_open(vs_ctx* ctx, uint16_t store_index, vs_store** o
 extern "C" int32_t vs_store_destroy(vs_store* s) {
     if (!s) return VS_OK;
     (void)hipSetDevice(s->ctx->device);
-    (void)hipDeviceSynchronize();
     {
         std::lock_guard<std::mutex> g(s->ctx->mu);
         s->ctx->stores.erase(s->index);
     }
+    {
+        std::lock_guard<std::mutex> g(s->ctx->upload_mu);
+        (void)quiesce(s);  // searches in flight finish; nobody may start one on a destroyed store
+        for (auto& kv : s->upload_events) {
+            (void)hipEventSynchronize(kv.second);
+            (void)hipEventDestroy(kv.second);
+        }
+    }
+    for (int i = 0; i < 2; ++i)
+        for (auto& kv : s->stream_events[i]) (void)hipEventDestroy(kv.second);
     if (s->d_rows) (void)hipFree(s->d_rows);
     if (s->d_norms) (void)hipFree(s->d_norms);
     if (s->d_present[0]) (void)hipFree(s->d_present[0]);
     if (s->d_present[1]) (void)hipFree(s->d_present[1]);
+    if (s->d_pending) (void)hipFree(s->d_pending);
+    if (s->d_pending_slots) (void)hipFree(s->d_pending_slots);
     delete s;
     return VS_OK;
 }
 
 namespace {
+
 void mark_present(vs_store* s, uint64_t slot) {
     uint64_t& w = s->h_present[slot >> 6];
     const uint64_t bit = 1ull << (slot & 63);
@@ -684,6 +734,9 @@ void mark_present(vs_store* s, uint64_t slot) {
         w |= bit;
         ++s->n_items;
     }
+}
+
+void mark_dirty(vs_store* s, uint64_t slot) {
     if (!s->dirty) {
         s->dirty = true;
         s->dirty_lo = s->dirty_hi = slot;
@@ -692,6 +745,45 @@ void mark_present(vs_store* s, uint64_t slot) {
         if (slot > s->dirty_hi) s->dirty_hi = slot;
     }
 }
+
+bool visible(const vs_store* s, uint64_t slot) { return (s->h_visible[slot >> 6] >> (slot & 63)) & 1; }
+
+// Makes room for `rows` parked rows (contents kept).
+int32_t reserve_pending(vs_store* s, size_t rows) {
+    if (rows <= s->pending_cap_rows) return VS_OK;
+    size_t cap = s->pending_cap_rows ? s->pending_cap_rows * 2 : 1024;
+    while (cap < rows) cap *= 2;
+    unsigned char* fresh = nullptr;
+    HIP_TRY(hipMalloc(&fresh, cap * s->row_bytes()));
+    if (s->d_pending) {
+        const hipError_t e = hipMemcpy(fresh, s->d_pending, s->pending_cap_rows * s->row_bytes(),
+                                       hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(fresh);
+            return fail(VS_E_DEVICE, "copying parked rows failed: %s", hipGetErrorString(e));
+        }
+        (void)hipFree(s->d_pending);
+    }
+    s->d_pending = fresh;
+    s->pending_cap_rows = cap;
+    return VS_OK;
+}
+
+// Where the writer puts the row of `slot`: the slab itself while no search can see the slot,
+// else a parked row (a new one, or the one an earlier upload of this transaction took).
+uint64_t route_slot(vs_store* s, uint64_t slot) {
+    if (!visible(s, slot)) {
+        mark_dirty(s, slot);
+        return slot;
+    }
+    auto it = s->pending_of_slot.find(slot);
+    if (it != s->pending_of_slot.end()) return vs::INGEST_SIDE | it->second;
+    const uint64_t j = s->pending_slots.size();
+    s->pending_slots.push_back(slot);
+    s->pending_of_slot.emplace(slot, j);
+    return vs::INGEST_SIDE | j;
+}
+
 }  // namespace
 
 extern "C" int32_t vs_store_upload(vs_store* s, const uint32_t* docids, const float* rows,
@@ -699,26 +791,37 @@ extern "C" int32_t vs_store_upload(vs_store* s, const uint32_t* docids, const fl
     if (int32_t rc = check_store(s)) return rc;
     if (n == 0) return VS_OK;
     if (!docids || !rows) return fail(VS_E_INVALID_ARG, "null docids or rows");
+    vs_ctx* ctx = s->ctx;
+    std::lock_guard<std::mutex> g(ctx->upload_mu);
     for (uint64_t i = 0; i < n; ++i)
         if (docids[i] < s->docid_base || (uint64_t)docids[i] - s->docid_base >= s->capacity)
             return fail(VS_E_CAPACITY, "docid %u outside the store's range [%u, %llu)", docids[i],
                         s->docid_base, (unsigned long long)(s->docid_base + s->capacity));
-    vs_ctx* ctx = s->ctx;
-    std::lock_guard<std::mutex> g(ctx->upload_mu);
     if (!ctx->h_stage) HIP_TRY(hipHostMalloc(&ctx->h_stage, STAGE_BYTES, hipHostMallocDefault));
     if (!ctx->d_stage) HIP_TRY(hipMalloc(&ctx->d_stage, STAGE_BYTES));
-    const size_t per_row = (size_t)s->dim * 4 + 4;
-    const uint64_t chunk = STAGE_BYTES / per_row;
-    const vs::SlabView v = s->view();
+    const size_t per_row = (size_t)s->dim * 4 + 8;
+    const uint64_t chunk = (STAGE_BYTES - 8) / per_row;
+    const vs::SlabView v = s->view(0);  // geometry only
+    // arroy's add_item is last-write-wins: of several rows for one docid in this call only the
+    // last is written (two waves writing one slot would have no defined order)
+    std::unordered_map<uint32_t, uint64_t> last;
+    last.reserve(n);
+    for (uint64_t i = 0; i < n; ++i) last[docids[i]] = i;
+    const bool dups = last.size() != n;
     for (uint64_t at = 0; at < n; at += chunk) {
         const uint64_t m = n - at < chunk ? n - at : chunk;
-        const size_t row_b = (size_t)m * s->dim * 4;
-        memcpy(ctx->h_stage, rows + at * s->dim, row_b);
-        memcpy(ctx->h_stage + row_b, docids + at, (size_t)m * 4);
-        HIP_TRY(hipMemcpyAsync(ctx->d_stage, ctx->h_stage, row_b + (size_t)m * 4,
+        const size_t row_b = ((size_t)m * s->dim * 4 + 7) / 8 * 8;
+        memcpy(ctx->h_stage, rows + at * s->dim, (size_t)m * s->dim * 4);
+        uint64_t* dest = reinterpret_cast<uint64_t*>(ctx->h_stage + row_b);
+        for (uint64_t i = 0; i < m; ++i) {
+            const uint32_t d = docids[at + i];
+            dest[i] = dups && last[d] != at + i ? vs::INGEST_SKIP : route_slot(s, d - s->docid_base);
+        }
+        if (int32_t rc = reserve_pending(s, s->pending_slots.size())) return rc;
+        HIP_TRY(hipMemcpyAsync(ctx->d_stage, ctx->h_stage, row_b + (size_t)m * 8,
                                hipMemcpyHostToDevice, ctx->upload_stream));
-        HIP_TRY(vs::launch_ingest_f32(v, s->d_rows, reinterpret_cast<const float*>(ctx->d_stage),
-                                      reinterpret_cast<const uint32_t*>(ctx->d_stage + row_b), m,
+        HIP_TRY(vs::launch_ingest_f32(v, s->d_rows, s->d_pending, reinterpret_cast<const float*>(ctx->d_stage),
+                                      reinterpret_cast<const uint64_t*>(ctx->d_stage + row_b), m,
                                       ctx->upload_stream));
         HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
     }
@@ -734,11 +837,42 @@ extern "C" int32_t vs_store_upload_device(vs_store* s, uint32_t first_docid,
     if (first_docid < s->docid_base || (uint64_t)first_docid - s->docid_base + n > s->capacity)
         return fail(VS_E_CAPACITY, "docids [%u, %u + %llu) outside the store's range", first_docid,
                     first_docid, (unsigned long long)n);
-    const uint64_t slot0 = first_docid - s->docid_base;
-    HIP_TRY(hipMemcpyAsync(static_cast<unsigned char*>(s->d_rows) + slot0 * s->row_bytes(),
-                           device_rows, (size_t)n * s->row_bytes(), hipMemcpyDeviceToDevice,
-                           static_cast<hipStream_t>(hip_stream)));
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     std::lock_guard<std::mutex> g(s->ctx->upload_mu);
+    const uint64_t slot0 = first_docid - s->docid_base;
+    const size_t rb = s->row_bytes();
+    const unsigned char* src = static_cast<const unsigned char*>(device_rows);
+    bool any_visible = false;
+    for (uint64_t w = slot0 >> 6; w <= (slot0 + n - 1) >> 6 && !any_visible; ++w) any_visible = s->h_visible[w] != 0;
+    if (any_visible) {  // a visible slot in the covering words: look slot by slot
+        any_visible = false;
+        for (uint64_t i = 0; i < n && !any_visible; ++i) any_visible = visible(s, slot0 + i);
+    }
+    if (!any_visible) {
+        // the bulk-load case: nothing a search can see is touched, one copy
+        HIP_TRY(hipMemcpyAsync(static_cast<unsigned char*>(s->d_rows) + slot0 * rb, src, (size_t)n * rb,
+                               hipMemcpyDeviceToDevice, stream));
+        mark_dirty(s, slot0);
+        mark_dirty(s, slot0 + n - 1);
+    } else {
+        // rows that replace visible items are parked; copies go run by run
+        std::vector<uint64_t> dest(n);
+        for (uint64_t i = 0; i < n; ++i) dest[i] = route_slot(s, slot0 + i);
+        if (int32_t rc = reserve_pending(s, s->pending_slots.size())) return rc;
+        for (uint64_t i = 0; i < n;) {
+            uint64_t j = i + 1;
+            while (j < n && dest[j] == dest[j - 1] + 1) ++j;  // consecutive slots, or consecutive parked rows
+            unsigned char* dst = (dest[i] & vs::INGEST_SIDE)
+                                     ? s->d_pending + (dest[i] & ~vs::INGEST_SIDE) * rb
+                                     : static_cast<unsigned char*>(s->d_rows) + dest[i] * rb;
+            HIP_TRY(hipMemcpyAsync(dst, src + i * rb, (size_t)(j - i) * rb, hipMemcpyDeviceToDevice, stream));
+            i = j;
+        }
+    }
+    // the seal waits for this copy through the stream's event, not through a device-wide wait
+    hipEvent_t& ev = s->upload_events[stream];
+    if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ev, stream));
     for (uint64_t i = 0; i < n; ++i) mark_present(s, slot0 + i);
     return VS_OK;
 }
@@ -764,18 +898,51 @@ extern "C" int32_t vs_store_seal(vs_store* s) {
     if (int32_t rc = check_store(s)) return rc;
     vs_ctx* ctx = s->ctx;
     std::lock_guard<std::mutex> g(ctx->upload_mu);
-    // uploads may have been enqueued on caller streams
-    HIP_TRY(hipDeviceSynchronize());
-    if (s->dirty && s->metric == VS_ANGULAR) {
-        const vs::SlabView v = s->view();
-        HIP_TRY(vs::launch_norms(v, s->d_norms, s->dirty_lo, s->dirty_hi - s->dirty_lo + 1,
-                                 ctx->upload_stream));
+    hipStream_t st = ctx->upload_stream;
+    // rows copied on caller streams (vs_store_upload_device) have arrived
+    for (auto& kv : s->upload_events) HIP_TRY(hipEventSynchronize(kv.second));
+    // norms of the rows written in place: slots no search can see yet (for the visible, unchanged
+    // slots inside the range the kernel rewrites the value that is already there)
+    if (s->dirty && s->metric == VS_ANGULAR)
+        HIP_TRY(vs::launch_norms(s->view(0), s->d_norms, s->dirty_lo, s->dirty_hi - s->dirty_lo + 1, st));
+    int next;
+    {
+        std::unique_lock<std::mutex> lk(s->snap_mu);
+        next = 1 - s->active;
+        // stragglers of the generation before the current one still read the buffer filled next
+        if (int32_t rc = wait_readers(s, next, lk)) return rc;
     }
-    const int next = 1 - s->active.load();
-    HIP_TRY(hipMemcpyAsync(s->d_present[next], s->h_present.data(), s->h_present.size() * 8,
-                           hipMemcpyHostToDevice, ctx->upload_stream));
-    HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
-    s->active.store(next, std::memory_order_release);
+    const size_t n_parked = s->pending_slots.size();
+    auto body = [&]() -> int32_t {
+        if (n_parked) {
+            // parked rows replace rows searches can see: the slab is rewritten with no search in flight
+            if (int32_t rc = vsrt::grow(&s->d_pending_slots, &s->pending_slots_bytes, n_parked * 8)) return rc;
+            HIP_TRY(hipMemcpyAsync(s->d_pending_slots, s->pending_slots.data(), n_parked * 8,
+                                   hipMemcpyHostToDevice, st));
+            if (int32_t rc = quiesce(s)) return rc;
+            const vs::SlabView v = s->view(0);
+            HIP_TRY(vs::launch_scatter_rows(v, s->d_rows, s->d_pending, s->d_pending_slots, n_parked, st));
+            if (s->metric == VS_ANGULAR)
+                HIP_TRY(vs::launch_norms_slots(v, s->d_norms, s->d_pending_slots, n_parked, st));
+        }
+        HIP_TRY(hipMemcpyAsync(s->d_present[next], s->h_present.data(), s->h_present.size() * 8,
+                               hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return VS_OK;
+    };
+    const int32_t rc = body();
+    {
+        std::lock_guard<std::mutex> lk(s->snap_mu);
+        if (rc == VS_OK) s->active = next;
+        s->writer_blocks = false;
+        s->snap_cv.notify_all();
+    }
+    if (rc != VS_OK) return rc;
+    // the buffer that was active keeps the previous generation for its stragglers
+    for (size_t w = 0; w < s->h_present.size(); ++w) s->h_visible[w] = s->h_present[w] | s->h_sealed[w];
+    s->h_sealed = s->h_present;
+    s->pending_slots.clear();
+    s->pending_of_slot.clear();
     s->sealed_items.store(s->n_items);
     s->dirty = false;
     s->sealed.store(true);
@@ -814,26 +981,33 @@ extern "C" int32_t vs_store_contains(vs_store* s, uint32_t docid, int32_t* out) 
 extern "C" int32_t vs_store_item_vector(vs_store* s, uint32_t docid, float* out) {
     if (int32_t rc = check_store(s)) return rc;
     if (!out) return fail(VS_E_INVALID_ARG, "null output");
-    int32_t has = 0;
-    vs_store_contains(s, docid, &has);
-    if (!has) return fail(VS_E_INVALID_ARG, "item %u is not in store %u", docid, s->index);
-    std::vector<unsigned char> row(s->row_bytes());
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(row.data(),
-                      static_cast<unsigned char*>(s->d_rows) +
-                          (uint64_t)(docid - s->docid_base) * s->row_bytes(),
-                      row.size(), hipMemcpyDeviceToHost));
+    vs_ctx* ctx = s->ctx;
+    std::lock_guard<std::mutex> g(ctx->upload_mu);
+    const bool in_range = docid >= s->docid_base && (uint64_t)docid - s->docid_base < s->capacity;
+    const uint64_t slot = in_range ? docid - s->docid_base : 0;
+    if (!in_range || !((s->h_present[slot >> 6] >> (slot & 63)) & 1))
+        return fail(VS_E_INVALID_ARG, "item %u is not in store %u", docid, s->index);
+    // the writer's view: a row parked by this transaction wins over the slab's
+    for (auto& kv : s->upload_events) HIP_TRY(hipEventSynchronize(kv.second));
+    const size_t rb = s->row_bytes();
+    auto it = s->pending_of_slot.find(slot);
+    const unsigned char* src = it != s->pending_of_slot.end()
+                                   ? s->d_pending + it->second * rb
+                                   : static_cast<const unsigned char*>(s->d_rows) + slot * rb;
+    unsigned char* row = ctx->h_small;
+    HIP_TRY(hipMemcpyAsync(row, src, rb, hipMemcpyDeviceToHost, ctx->upload_stream));
+    HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
     for (uint32_t e = 0; e < s->dim; ++e) {
         if (s->dtype == VS_F32) {
-            memcpy(&out[e], row.data() + 4 * e, 4);
+            memcpy(&out[e], row + 4 * e, 4);
         } else if (s->dtype == VS_BF16) {
             uint16_t h;
-            memcpy(&h, row.data() + 2 * e, 2);
+            memcpy(&h, row + 2 * e, 2);
             const uint32_t u = (uint32_t)h << 16;
             memcpy(&out[e], &u, 4);
         } else {
             uint64_t w;
-            memcpy(&w, row.data() + 8 * (e / 64), 8);
+            memcpy(&w, row + 8 * (e / 64), 8);
             out[e] = (float)((w >> (e % 64)) & 1);
         }
     }
@@ -848,17 +1022,14 @@ extern "C" int32_t vs_search(vs_store* s, const float* query, uint32_t dim, uint
     if (int32_t rc = begin_search(s, query, dim, k, out_ids, out_dist, out_n)) return rc;
     *out_n = 0;
     if (k == 0) return VS_OK;
-    std::unique_ptr<Workspace> ws;
-    if (int32_t rc = ws_acquire(s->ctx, &ws)) return rc;
-    int32_t rc = VS_OK;
-    const uint64_t* d_cand = nullptr;
-    if (mask_words) {
-        rc = stage_dense_mask(s, ws.get(), mask_words, n_mask_words);
-        d_cand = ws->d_mask;
-    }
-    if (rc == VS_OK) rc = run_and_fetch(s, ws.get(), query, k, d_cand, out_ids, out_dist, out_n);
-    ws_release(s->ctx, std::move(ws));
-    return rc;
+    return with_snapshot(s, [&](Workspace* ws, const vs::SlabView& v) -> int32_t {
+        const uint64_t* d_cand = nullptr;
+        if (mask_words) {
+            if (int32_t rc = stage_dense_mask(s, ws, mask_words, n_mask_words)) return rc;
+            d_cand = ws->d_mask;
+        }
+        return run_and_fetch(s, v, ws, query, k, d_cand, out_ids, out_dist, out_n);
+    });
 }
 
 extern "C" int32_t vs_search_roaring(vs_store* s, const float* query, uint32_t dim, uint32_t k,
@@ -871,17 +1042,12 @@ extern "C" int32_t vs_search_roaring(vs_store* s, const float* query, uint32_t d
     if (!vs::roaring_parse(roaring_bytes, len, &desc))
         return fail(VS_E_FORMAT, "malformed serialised RoaringBitmap (%zu bytes)", len);
     if (k == 0) return VS_OK;
-    std::unique_ptr<Workspace> ws;
-    if (int32_t rc = ws_acquire(s->ctx, &ws)) return rc;
-    auto body = [&]() -> int32_t {
+    return with_snapshot(s, [&](Workspace* ws, const vs::SlabView& v) -> int32_t {
         const uint64_t n_words = s->n_slots / 64;
         if (int32_t rc = grow(&ws->d_mask, &ws->mask_words, (size_t)n_words * 8)) return rc;
-        if (int32_t rc = expand_roaring(s, ws.get(), roaring_bytes, len, desc, ws->d_mask)) return rc;
-        return run_and_fetch(s, ws.get(), query, k, ws->d_mask, out_ids, out_dist, out_n);
-    };
-    const int32_t rc = body();
-    ws_release(s->ctx, std::move(ws));
-    return rc;
+        if (int32_t rc = expand_roaring(s, ws, roaring_bytes, len, desc, ws->d_mask)) return rc;
+        return run_and_fetch(s, v, ws, query, k, ws->d_mask, out_ids, out_dist, out_n);
+    });
 }
 
 // ---- candidate masks kept on the device ------------------------------------------------------
@@ -892,7 +1058,6 @@ int32_t mask_new(vs_store* s, vs_mask** out, std::unique_ptr<vs_mask>* m) {
     *out = nullptr;
     if (int32_t rc = check_store(s)) return rc;
     m->reset(new vs_mask{s, nullptr, s->n_slots});
-    HIP_TRY(hipSetDevice(s->ctx->device));
     if (hipMalloc(&(*m)->d_words, (size_t)(s->n_slots / 64) * 8) != hipSuccess)
         return fail(VS_E_OOM, "cannot allocate a %llu-byte mask", (unsigned long long)(s->n_slots / 8));
     return VS_OK;
@@ -901,12 +1066,10 @@ int32_t mask_new(vs_store* s, vs_mask** out, std::unique_ptr<vs_mask>* m) {
 
 extern "C" int32_t vs_mask_create(vs_store* s, const uint64_t* mask_words, uint64_t n_mask_words,
                                   vs_mask** out) {
+    if (out) *out = nullptr;
+    if (!mask_words && n_mask_words) return fail(VS_E_INVALID_ARG, "null mask words");
     std::unique_ptr<vs_mask> m;
     if (int32_t rc = mask_new(s, out, &m)) return rc;
-    if (!mask_words && n_mask_words) {
-        (void)hipFree(m->d_words);
-        return fail(VS_E_INVALID_ARG, "null mask words");
-    }
     std::unique_ptr<Workspace> ws;
     int32_t rc = ws_acquire(s->ctx, &ws);
     if (rc == VS_OK) {
@@ -962,21 +1125,36 @@ extern "C" int32_t vs_mask_destroy(vs_mask* m) {
     return VS_OK;
 }
 
+namespace {
+int32_t check_mask(vs_store* s, const vs_mask* mask) {
+    if (mask && mask->store != s) return fail(VS_E_INVALID_ARG, "the mask was created for another store");
+    if (mask && mask->n_slots != s->n_slots)
+        return fail(VS_E_INVALID_ARG, "the mask was created before the store grew: create it again");
+    return VS_OK;
+}
+}  // namespace
+
 extern "C" int32_t vs_search_mask(vs_store* s, const float* query, uint32_t dim, uint32_t k,
                                   const vs_mask* mask, uint32_t* out_ids, float* out_dist,
                                   uint32_t* out_n) {
     if (int32_t rc = begin_search(s, query, dim, k, out_ids, out_dist, out_n)) return rc;
     *out_n = 0;
-    if (mask && mask->store != s) return fail(VS_E_INVALID_ARG, "the mask was created for another store");
-    if (mask && mask->n_slots != s->n_slots)
-        return fail(VS_E_INVALID_ARG, "the mask was created before the store grew: create it again");
+    if (int32_t rc = check_mask(s, mask)) return rc;
     if (k == 0) return VS_OK;
-    std::unique_ptr<Workspace> ws;
-    if (int32_t rc = ws_acquire(s->ctx, &ws)) return rc;
-    const int32_t rc = run_and_fetch(s, ws.get(), query, k, mask ? mask->d_words : nullptr, out_ids, out_dist, out_n);
-    ws_release(s->ctx, std::move(ws));
-    return rc;
+    return with_snapshot(s, [&](Workspace* ws, const vs::SlabView& v) -> int32_t {
+        return run_and_fetch(s, v, ws, query, k, mask ? mask->d_words : nullptr, out_ids, out_dist, out_n);
+    });
 }
+
+namespace {
+// n_q queries under ONE device-resident candidate mask (null = every item), host results.
+int32_t batch_under_mask(vs_store* s, const vs::SlabView& v, Workspace* ws, const float* queries, uint32_t n_q,
+                         uint32_t k, const uint64_t* d_cand, uint32_t* out_ids, float* out_dist, uint32_t* out_n) {
+    if (on_matrix_cores(s, k) && n_q > 1)
+        return run_batch_and_fetch(s, v, ws, queries, n_q, k, d_cand, out_ids, out_dist, out_n);
+    return run_many_and_fetch(s, v, ws, queries, n_q, k, d_cand, out_ids, out_dist, out_n);
+}
+}  // namespace
 
 extern "C" int32_t vs_search_batch(vs_store* s, const float* queries, uint32_t n_q, uint32_t dim,
                                    uint32_t k, const uint64_t* mask_words, uint64_t n_mask_words,
@@ -985,21 +1163,83 @@ extern "C" int32_t vs_search_batch(vs_store* s, const float* queries, uint32_t n
     if (int32_t rc = begin_search(s, queries, dim, k, out_ids, out_dist, out_n)) return rc;
     for (uint32_t i = 0; i < n_q; ++i) out_n[i] = 0;
     if (k == 0) return VS_OK;
-    std::unique_ptr<Workspace> ws;
-    if (int32_t rc = ws_acquire(s->ctx, &ws)) return rc;
-    int32_t rc = VS_OK;
-    const uint64_t* d_cand = nullptr;
-    if (mask_words) {
-        rc = stage_dense_mask(s, ws.get(), mask_words, n_mask_words);
-        d_cand = ws->d_mask;
+    return with_snapshot(s, [&](Workspace* ws, const vs::SlabView& v) -> int32_t {
+        const uint64_t* d_cand = nullptr;
+        if (mask_words) {
+            if (int32_t rc = stage_dense_mask(s, ws, mask_words, n_mask_words)) return rc;
+            d_cand = ws->d_mask;
+        }
+        return batch_under_mask(s, v, ws, queries, n_q, k, d_cand, out_ids, out_dist, out_n);
+    });
+}
+
+extern "C" int32_t vs_search_batch_masks(vs_store* s, const float* queries, uint32_t n_q, uint32_t dim,
+                                         uint32_t k, const uint64_t* const* mask_words,
+                                         const uint64_t* n_mask_words, const vs_mask* const* masks,
+                                         uint32_t* out_ids, float* out_dist, uint32_t* out_n) {
+    if (n_q == 0) return VS_OK;
+    if (int32_t rc = begin_search(s, queries, dim, k, out_ids, out_dist, out_n)) return rc;
+    if (mask_words && !n_mask_words) return fail(VS_E_INVALID_ARG, "mask words without their lengths");
+    for (uint32_t i = 0; i < n_q; ++i) {
+        out_n[i] = 0;
+        if (masks && masks[i])
+            if (int32_t rc = check_mask(s, masks[i])) return rc;
     }
-    if (rc == VS_OK && on_matrix_cores(s, k) && n_q > 1) {
-        rc = run_batch_and_fetch(s, ws.get(), queries, n_q, k, d_cand, out_ids, out_dist, out_n);
-    } else if (rc == VS_OK) {
-        rc = run_many_and_fetch(s, ws.get(), queries, n_q, k, d_cand, out_ids, out_dist, out_n);
+    if (k == 0) return VS_OK;
+    // Queries with the same filter (the same vs_mask, the same host words, or none) form a group
+    // that shares passes exactly as vs_search_batch would; every group is searched under its own
+    // mask, so a scan reads only that filter's candidates.
+    struct Filter {
+        const vs_mask* mask;
+        const uint64_t* words;
+        uint64_t n_words;
+        bool operator<(const Filter& o) const {
+            if (mask != o.mask) return mask < o.mask;
+            if (words != o.words) return words < o.words;
+            return n_words < o.n_words;
+        }
+    };
+    std::map<Filter, std::vector<uint32_t>> groups;
+    for (uint32_t i = 0; i < n_q; ++i) {
+        Filter f{masks ? masks[i] : nullptr, nullptr, 0};
+        if (!f.mask && mask_words && mask_words[i]) {
+            f.words = mask_words[i];
+            f.n_words = n_mask_words[i];
+        }
+        groups[f].push_back(i);
     }
-    ws_release(s->ctx, std::move(ws));
-    return rc;
+    return with_snapshot(s, [&](Workspace* ws, const vs::SlabView& v) -> int32_t {
+        std::vector<float> q;
+        std::vector<uint32_t> ids, cnt;
+        std::vector<float> dist;
+        for (auto& kv : groups) {
+            const Filter& f = kv.first;
+            const std::vector<uint32_t>& members = kv.second;
+            const uint64_t* d_cand = nullptr;
+            if (f.mask) {
+                d_cand = f.mask->d_words;
+            } else if (f.words) {
+                if (int32_t rc = stage_dense_mask(s, ws, f.words, f.n_words)) return rc;
+                d_cand = ws->d_mask;
+            }
+            const uint32_t m = (uint32_t)members.size();
+            q.resize((size_t)m * dim);
+            for (uint32_t j = 0; j < m; ++j)
+                memcpy(q.data() + (size_t)j * dim, queries + (size_t)members[j] * dim, (size_t)dim * 4);
+            ids.assign((size_t)m * k, 0);
+            dist.assign((size_t)m * k, 0.0f);
+            cnt.assign(m, 0);
+            if (int32_t rc = batch_under_mask(s, v, ws, q.data(), m, k, d_cand, ids.data(), dist.data(), cnt.data()))
+                return rc;
+            for (uint32_t j = 0; j < m; ++j) {
+                const uint32_t i = members[j];
+                memcpy(out_ids + (size_t)i * k, ids.data() + (size_t)j * k, (size_t)cnt[j] * 4);
+                memcpy(out_dist + (size_t)i * k, dist.data() + (size_t)j * k, (size_t)cnt[j] * 4);
+                out_n[i] = cnt[j];
+            }
+        }
+        return VS_OK;
+    });
 }
 
 // ---- search, device buffers ------------------------------------------------------------------
@@ -1007,7 +1247,7 @@ extern "C" int32_t vs_search_batch(vs_store* s, const float* queries, uint32_t n
 extern "C" int32_t vs_search_workspace_bytes(vs_store* s, uint32_t k, uint64_t* bytes) {
     if (!s || !bytes) return fail(VS_E_INVALID_ARG, "null argument");
     if (k == 0 || k > VS_MAX_K) return fail(VS_E_INVALID_ARG, "k = %u out of range", k);
-    *bytes = vs::scan_partial_bytes(s->view(), k, s->ctx->tuning);
+    *bytes = vs::scan_workspace_bytes(s->view(0), k);
     return VS_OK;
 }
 
@@ -1016,62 +1256,90 @@ extern "C" int32_t vs_search_device(vs_store* s, const void* d_query, uint32_t d
                                     uint64_t* d_out_keys, void* hip_stream) {
     if (int32_t rc = check_store(s)) return rc;
     if (!d_query || !d_workspace || !d_out_keys) return fail(VS_E_INVALID_ARG, "null device buffer");
-    if (!s->sealed.load()) return fail(VS_E_NOT_SEALED, "store %u was never sealed", s->index);
-    if (dim != s->dim) {
-        g_dim_expected = s->dim;
-        g_dim_received = dim;
-        return fail(VS_E_DIM_MISMATCH, "invalid vector dimensions: expected %u, received %u", s->dim,
-                    dim);
-    }
-    if (k == 0 || k > VS_MAX_K) return fail(VS_E_INVALID_ARG, "k = %u out of range", k);
-    return launch_scan(s, s->ctx->tuning, d_query, d_mask_words, k, static_cast<uint64_t*>(d_workspace),
-                       d_out_keys, nullptr, nullptr, nullptr, static_cast<hipStream_t>(hip_stream));
+    if (int32_t rc = check_device_search(s, dim, k)) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    Snapshot snap;
+    snapshot_begin(s, &snap);
+    const int32_t rc = launch_scan(snap.v, tuning_of(s->ctx), d_query, d_mask_words, k,
+                                   static_cast<uint64_t*>(d_workspace), d_out_keys, nullptr, nullptr, nullptr,
+                                   stream);
+    const int32_t rc2 = snapshot_end_async(s, &snap, stream, true);
+    return rc ? rc : rc2;
 }
 
 // vs_search_device without a workspace argument and without any allocation: the scan's partial
 // lists go to this GPU's static scratch array. The scan overwrites every entry of the partial
 // buffer it later merges (each workgroup writes its k keys, padded with VS_KEY_NONE), so nothing
 // needs clearing between calls; calls that overlap on one GPU would share the array and race.
+// No event is recorded for the search (the stream may be under graph capture, and creating an
+// event allocates): the caller orders these searches against vs_store_seal itself.
 extern "C" int32_t vs_search_device_noalloc(vs_store* s, const void* d_query, uint32_t dim, uint32_t k,
                                             const uint64_t* d_mask_words, uint64_t* d_out_keys,
                                             void* hip_stream) {
     if (int32_t rc = check_store(s)) return rc;
     if (!d_query || !d_out_keys) return fail(VS_E_INVALID_ARG, "null device buffer");
-    if (!s->sealed.load()) return fail(VS_E_NOT_SEALED, "store %u was never sealed", s->index);
-    if (dim != s->dim) {
-        g_dim_expected = s->dim;
-        g_dim_received = dim;
-        return fail(VS_E_DIM_MISMATCH, "invalid vector dimensions: expected %u, received %u", s->dim,
-                    dim);
-    }
-    if (k == 0 || k > VS_MAX_K) return fail(VS_E_INVALID_ARG, "k = %u out of range", k);
-    const vs::ScanTuning t = s->ctx->tuning;  // one snapshot: the size check and the launch agree
-    const uint64_t need = vs::scan_partial_bytes(s->view(), k, t);
+    if (int32_t rc = check_device_search(s, dim, k)) return rc;
+    const vs::ScanTuning t = tuning_of(s->ctx);  // one snapshot: the size check and the launch agree
+    Snapshot snap;
+    snapshot_begin(s, &snap);
+    const uint64_t need = vs::scan_partial_bytes(snap.v, k, t);
+    int32_t rc;
     if (need > NOALLOC_SCRATCH_BYTES)
-        return fail(VS_E_CAPACITY,
-                    "vs_search_device_noalloc: this store and k = %u need %llu bytes of partial lists, the "
-                    "static scratch holds %llu (use vs_search_device with a workspace)",
-                    k, (unsigned long long)need, (unsigned long long)NOALLOC_SCRATCH_BYTES);
-    return launch_scan(s, t, d_query, d_mask_words, k, reinterpret_cast<uint64_t*>(s->ctx->d_scratch),
-                       d_out_keys, nullptr, nullptr, nullptr, static_cast<hipStream_t>(hip_stream));
+        rc = fail(VS_E_CAPACITY,
+                  "vs_search_device_noalloc: this store and k = %u need %llu bytes of partial lists, the "
+                  "static scratch holds %llu (use vs_search_device with a workspace)",
+                  k, (unsigned long long)need, (unsigned long long)NOALLOC_SCRATCH_BYTES);
+    else
+        rc = launch_scan(snap.v, t, d_query, d_mask_words, k, reinterpret_cast<uint64_t*>(s->ctx->d_scratch),
+                         d_out_keys, nullptr, nullptr, nullptr, static_cast<hipStream_t>(hip_stream));
+    (void)snapshot_end_async(s, &snap, nullptr, false);
+    return rc;
 }
 
-extern "C" int32_t vs_search_batch_workspace_bytes(vs_store* s, uint32_t k, uint64_t* bytes) {
-    if (!s || !bytes) return fail(VS_E_INVALID_ARG, "null argument");
-    const vs::SlabView v = s->view();
+namespace vsrt {
+
+uint64_t batch_workspace_bytes_for(vs_store* s, const vs::SlabView& v, uint32_t k, bool* served) {
+    *served = true;
+    if (on_matrix_cores(s, k)) return vs::batch_workspace_bytes(v, k);
+    if (vs::scan_hamming_multi_serves(v, k)) return vs::scan_workspace_bytes(v, k) * 4;
+    if (shared_pass_serves(v, k)) return shared_pass_partial_bytes(v, k);
+    *served = false;
+    return 0;
+}
+
+int32_t launch_batch(vs_store* s, const vs::SlabView& v, const vs::ScanTuning& t, const void* d_queries,
+                     uint32_t n_q, uint32_t k, const uint64_t* d_mask_words, void* d_workspace,
+                     uint64_t* d_out_keys, hipStream_t stream) {
     if (on_matrix_cores(s, k)) {
-        *bytes = vs::batch_workspace_bytes(v, k);
+        HIP_TRY(vs::launch_scan_batch_bf16(v, static_cast<const float*>(d_queries), n_q, d_mask_words, k,
+                                           d_workspace, d_out_keys, nullptr, nullptr, nullptr, stream));
         return VS_OK;
     }
     if (vs::scan_hamming_multi_serves(v, k)) {
-        *bytes = vs::scan_partial_bytes(v, k, s->ctx->tuning) * 4;
+        // binary store: d_queries holds n_q packed queries, vs_store_row_bytes bytes each
+        const unsigned char* bits = static_cast<const unsigned char*>(d_queries);
+        for (uint32_t i = 0; i < n_q; i += 4)
+            HIP_TRY(vs::launch_scan_hamming_multi(v, bits + (size_t)i * s->row_bytes(), s->row_vecs,
+                                                  n_q - i < 4 ? n_q - i : 4, d_mask_words, k,
+                                                  static_cast<uint64_t*>(d_workspace),
+                                                  d_out_keys + (size_t)i * k, nullptr, nullptr, nullptr, t, stream));
         return VS_OK;
     }
-    if (!shared_pass_serves(v, k))
+    if (!shared_pass_serves(v, k)) return fail(VS_E_INVALID_ARG, "no batched scan for this store and k = %u", k);
+    return queue_shared_passes(v, t, static_cast<const float*>(d_queries), s->dim, n_q, d_mask_words, k,
+                               static_cast<uint64_t*>(d_workspace), d_out_keys, nullptr, nullptr, nullptr, stream);
+}
+
+}  // namespace vsrt
+
+extern "C" int32_t vs_search_batch_workspace_bytes(vs_store* s, uint32_t k, uint64_t* bytes) {
+    if (!s || !bytes) return fail(VS_E_INVALID_ARG, "null argument");
+    bool served;
+    *bytes = batch_workspace_bytes_for(s, s->view(0), k, &served);
+    if (!served)
         return fail(VS_E_INVALID_ARG,
                     "no batched scan for this store and k = %u (angular bf16 rows with k <= %u; f32 rows "
                     "of up to 1536 or bf16 rows of up to 1536 dimensions with k <= 128)", k, VS_BATCH_MAX_K);
-    *bytes = shared_pass_partial_bytes(v, k, s->ctx->tuning);
     return VS_OK;
 }
 
@@ -1080,38 +1348,16 @@ extern "C" int32_t vs_search_batch_device(vs_store* s, const float* d_queries, u
                                           void* d_workspace, uint64_t* d_out_keys, void* hip_stream) {
     if (int32_t rc = check_store(s)) return rc;
     if (!d_queries || !d_workspace || !d_out_keys) return fail(VS_E_INVALID_ARG, "null device buffer");
-    if (!s->sealed.load()) return fail(VS_E_NOT_SEALED, "store %u was never sealed", s->index);
-    if (dim != s->dim) {
-        g_dim_expected = s->dim;
-        g_dim_received = dim;
-        return fail(VS_E_DIM_MISMATCH, "invalid vector dimensions: expected %u, received %u", s->dim,
-                    dim);
-    }
+    if (int32_t rc = check_device_search(s, dim, k)) return rc;
     if (n_q == 0 || n_q > VS_BATCH_MAX_QUERIES)
         return fail(VS_E_INVALID_ARG, "n_q = %u out of range", n_q);
-    const vs::SlabView v = s->view();
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    if (on_matrix_cores(s, k)) {
-        HIP_TRY(vs::launch_scan_batch_bf16(v, d_queries, n_q, d_mask_words, k, d_workspace, d_out_keys,
-                                           nullptr, nullptr, nullptr, stream));
-        return VS_OK;
-    }
-    if (vs::scan_hamming_multi_serves(v, k)) {
-        // binary store: d_queries holds n_q packed queries, vs_store_row_bytes bytes each
-        const unsigned char* bits = reinterpret_cast<const unsigned char*>(d_queries);
-        for (uint32_t i = 0; i < n_q; i += 4)
-            HIP_TRY(vs::launch_scan_hamming_multi(v, bits + (size_t)i * s->row_bytes(), s->row_vecs,
-                                                  n_q - i < 4 ? n_q - i : 4, d_mask_words, k,
-                                                  static_cast<uint64_t*>(d_workspace),
-                                                  d_out_keys + (size_t)i * k, nullptr, nullptr, nullptr,
-                                                  s->ctx->tuning, stream));
-        return VS_OK;
-    }
-    if (!shared_pass_serves(v, k))
-        return fail(VS_E_INVALID_ARG, "no batched scan for this store and k = %u", k);
-    return queue_shared_passes(v, s->ctx->tuning, d_queries, dim, n_q, d_mask_words, k,
-                               static_cast<uint64_t*>(d_workspace), d_out_keys, nullptr, nullptr, nullptr,
-                               stream);
+    Snapshot snap;
+    snapshot_begin(s, &snap);
+    const int32_t rc = launch_batch(s, snap.v, tuning_of(s->ctx), d_queries, n_q, k, d_mask_words, d_workspace,
+                                    d_out_keys, stream);
+    const int32_t rc2 = snapshot_end_async(s, &snap, stream, true);
+    return rc ? rc : rc2;
 }
 
 extern "C" int32_t vs_merge_topk_device(vs_ctx* ctx, const uint64_t* d_keys, uint32_t n_lists,
