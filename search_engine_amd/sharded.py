@@ -1,4 +1,9 @@
-"""One logical store sharded over the ranks of a torch.distributed job.
+"""Host-side helpers for one logical store sharded over several ranks.
+
+On the GPU the whole sharded search is one C-ABI call (vs_search_sharded_device: local
+scans, the RCCL all-gather, the merge). This module holds what a host needs around it —
+the shard arithmetic — plus CPU restatements of the key format and of the merge's layout
+contract, with which the tests rehearse the multi-rank data flow under gloo.
 
 Documents are split into contiguous docid ranges, one per rank (one process per
 GPU), boundaries on multiples of 64 so that a dense candidate mask slices by
@@ -55,9 +60,9 @@ class ShardedSearch:
     local_search(j, out_keys) must leave the shard-local ascending top-k keys of
     the batch's j-th query in out_keys (an int64 tensor view of k entries, padded
     with KEY_NONE); merge(gathered, world, n_queries, k) turns the all-gathered
-    keys [world][n_queries][k] into (ids, distances, counts). On the GPU those are
-    vs_search_device and vs_merge_topk_batch_device; tests inject CPU stand-ins to
-    exercise the sharding and the collective under gloo.
+    keys [world][n_queries][k] into (ids, distances, counts). The GPU library does all of
+    this inside vs_search_sharded_device; the tests inject CPU stand-ins here to exercise the
+    sharding and the collective's layout under gloo.
     """
 
     def __init__(self, local_search, merge, k, batch, device, group=None, local_search_all=None,
@@ -91,53 +96,17 @@ class ShardedSearch:
         return self.merge(self.gathered, self.world, n, self.k)
 
 
-def gpu_sharded_search(ctx, store, k, batch, device, query_ptr, mask_ptr, stream, group=None,
-                       metric=0, always_gather=False):
-    """ShardedSearch over libvs_amd.so. query_ptr(j) -> device address of the j-th query of the
-    current batch; mask_ptr -> device address of the shard-aligned candidate words (0 = none)."""
-    from . import abi
-    ws = torch.empty(store.workspace_bytes(k), dtype=torch.uint8, device=device)
-    out_ids = torch.empty(batch * k, dtype=torch.int32, device=device)
-    out_dist = torch.empty(batch * k, dtype=torch.float32, device=device)
-    out_n = torch.empty(batch, dtype=torch.int32, device=device)
-    dim = store.dim
-
-    def local_search(j, out_keys):
-        store.search_device(query_ptr(j), dim, k, mask_ptr(), ws.data_ptr(), out_keys.data_ptr(), stream())
-
-    def merge(gathered, world, n_queries, kk):
-        ctx.merge_topk_batch_device(gathered.data_ptr(), world, batch * kk, n_queries, kk, kk,
-                                    metric, out_ids.data_ptr(), out_dist.data_ptr(),
-                                    out_n.data_ptr(), stream())
-        return out_ids, out_dist, out_n
-
-    s = ShardedSearch(local_search, merge, k, batch, device, group, always_gather=always_gather)
-    s.workspace = ws  # keep alive
-    return s
-
-
-def gpu_sharded_batch_search(ctx, store, k, batch, device, queries_ptr, mask_ptr, stream, group=None,
-                             always_gather=False):
-    """ShardedSearch whose local step is ONE vs_search_batch_device call (bf16 store, k <= 32,
-    batch <= 256: the scan on the matrix cores). queries_ptr() -> device address of the batch's
-    f32 queries [batch][dim]."""
-    from . import abi
-    ws = torch.empty(store.batch_workspace_bytes(k), dtype=torch.uint8, device=device)
-    out_ids = torch.empty(batch * k, dtype=torch.int32, device=device)
-    out_dist = torch.empty(batch * k, dtype=torch.float32, device=device)
-    out_n = torch.empty(batch, dtype=torch.int32, device=device)
-    dim = store.dim
-
-    def local_search_all(n, keys):
-        store.search_batch_device(queries_ptr(), n, dim, k, mask_ptr(), ws.data_ptr(), keys.data_ptr(), stream())
-
-    def merge(gathered, world, n_queries, kk):
-        ctx.merge_topk_batch_device(gathered.data_ptr(), world, batch * kk, n_queries, kk, kk,
-                                    abi.VS_ANGULAR, out_ids.data_ptr(), out_dist.data_ptr(),
-                                    out_n.data_ptr(), stream())
-        return out_ids, out_dist, out_n
-
-    s = ShardedSearch(None, merge, k, batch, device, group, local_search_all=local_search_all,
-                      always_gather=always_gather)
-    s.workspace = ws  # keep alive
-    return s
+def merge_keys_cpu(keys, n_lists, list_stride, n_queries, query_stride, k):
+    """Host restatement of the merge launch's layout contract (vs_merge_topk_batch_device): list i
+    of query q starts at keys[q * query_stride + i * list_stride] and holds k ascending keys padded
+    with KEY_NONE; the result per query is the k smallest keys of its lists, ascending (keys are
+    unique: a docid lives in one shard), padded with KEY_NONE. For the all-gathered layout
+    [rank][query][k]: list_stride = n_queries * k, query_stride = k. Returns u64 [n_queries][k]."""
+    keys = np.ascontiguousarray(keys).view(np.uint64).reshape(-1)
+    out = np.full((n_queries, k), KEY_NONE, np.uint64)
+    for q in range(n_queries):
+        lists = [keys[q * query_stride + i * list_stride: q * query_stride + i * list_stride + k]
+                 for i in range(n_lists)]
+        merged = np.sort(np.concatenate(lists))[:k]
+        out[q, : merged.size] = merged
+    return out

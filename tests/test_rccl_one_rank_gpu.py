@@ -1,7 +1,9 @@
 """The multi-rank code path of bench.py under RCCL, rehearsed with a one-rank group on a single
-GPU (VS_BENCH_FORCE_DIST=1): process-group set-up next to the library's own HIP runtime use,
-barrier, all_gather_into_tensor of the keys, the batch merge, the all-reduce of the time. The
-sharding arithmetic itself is covered for world sizes 2 and 3 in tests/test_sharded_gloo.py."""
+GPU (VS_BENCH_FORCE_DIST=1): process-group set-up next to the library's own HIP runtime use and
+its own RCCL communicator, the broadcast of the group id, barrier, the all-gather of the keys
+inside vs_search_sharded_device, the batch merge, the all-reduce of the time. The launcher that
+starts the ranks is covered on the CPU in tests/test_bench_launch.py, the sharding arithmetic for
+world sizes 2 and 3 in tests/test_sharded_gloo.py."""
 import json
 import os
 import subprocess
@@ -33,9 +35,28 @@ def test_single_query_bench_under_a_one_rank_rccl_group():
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] == "strong"
     for key in ("metric", "unit", "ms_per_step", "roofline", "cpu_baseline", "config", "dtype", "data"):
         assert key in line
-    assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and line["config"]["ranks_in_group"] == 1
+    # the accounting, not the speed: bytes = passing rows * (row + norm) + mask, rate = bytes / launch time
+    n_pass = (r["algorithmic_bytes_per_launch"] - 300032 // 8) / (768 * 4 + 4)
+    assert 0.45 * 300000 < n_pass < 0.55 * 300000
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 0.02 * r["achieved"]
+    assert abs(r["frac"] - r["achieved"] / 8000.0) < 1e-3 and 0.02 < r["frac"] < 1
+
+
+def test_hamming_bench_line():
+    line = bench("--docs", "2000000", "--dtype", "bin1", force_dist=False)
+    r = line["roofline"]
+    assert line["config"]["k"] == 100 and line["config"]["dim"] == 1536
+    assert r["algorithmic_bytes_per_launch"] == 2000000 * 192 + 2000000 // 8 and 0.02 < r["frac"] < 1
 
 
 def test_batched_bench_under_a_one_rank_rccl_group():
     line = bench("--docs", "200000", "--dtype", "bf16", "--batch-queries", "256", force_dist=True)
     assert line["n_gpus"] == 1 and line["value"] > 0
+    assert 0 < line["roofline"]["frac"] < 1 and 0 < line["roofline"]["mfma_frac"] < 1
+
+
+def test_shared_pass_f32_bench_line_stays_below_the_roofline():
+    line = bench("--docs", "400000", "--batch-queries", "64", "--pass-percent", "10", force_dist=False)
+    assert 0 < line["roofline"]["frac"] < 1 and line["roofline"]["passes_per_step"] == 2

@@ -1,0 +1,156 @@
+"""The pieces of the multi-GPU path that one GPU can run for real: the merge launch on a gathered
+[rank][query][k] buffer, eight docid-range shards searched and merged on one device, and
+vs_search_sharded_device itself in a group of one (with and without the collective). What is left
+for a multi-GPU node is RCCL moving bytes between processes."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import facet_mask, synthetic_vectors
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def _merge_on_gpu(ctx, keys, n_lists, list_stride, n_queries, query_stride, k, metric=0):
+    d_keys = torch.from_numpy(np.ascontiguousarray(keys).view(np.int64)).to(DEV)
+    ids = torch.zeros(n_queries * k, dtype=torch.int32, device=DEV)
+    dist = torch.zeros(n_queries * k, dtype=torch.float32, device=DEV)
+    cnt = torch.zeros(n_queries, dtype=torch.int32, device=DEV)
+    ctx.merge_topk_batch_device(d_keys.data_ptr(), n_lists, list_stride, n_queries, query_stride, k, metric,
+                                ids.data_ptr(), dist.data_ptr(), cnt.data_ptr(),
+                                torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return (ids.cpu().numpy().view(np.uint32).reshape(n_queries, k), dist.cpu().numpy().reshape(n_queries, k),
+            cnt.cpu().numpy())
+
+
+@pytest.mark.parametrize("world,n_queries,k", [(8, 16, 10), (8, 3, 100), (2, 256, 10), (5, 7, 1), (8, 4, 300)])
+def test_merge_of_a_gathered_buffer_follows_the_layout_contract(gpu_ctx, world, n_queries, k):
+    """Synthetic [world][query][k] keys: short lists padded with VS_KEY_NONE, empty shards, distances
+    that tie exactly across shards (the docid decides), one query with fewer than k hits overall."""
+    from search_engine_amd import sharded
+    rng = np.random.default_rng(world * 1000 + k)
+    gathered = np.full((world, n_queries, k), sharded.KEY_NONE, np.uint64)
+    for q in range(n_queries):
+        few = q == n_queries - 1  # the last query: fewer than k hits in all shards together
+        levels = rng.random(6).astype(np.float32)  # a handful of distance values: many exact ties
+        for r in range(world):
+            n = int(rng.integers(0, k + 1))
+            if few:
+                n = min(n, max(0, (k - 1) // world))
+            if r == 1 % world and q % 2 == 0:
+                n = 0  # an empty shard
+            ids = rng.choice(np.arange(r * 100_000, (r + 1) * 100_000, dtype=np.uint32), n, replace=False)
+            d = rng.choice(levels, n) if q % 3 else rng.random(n).astype(np.float32)
+            keys = np.sort(sharded.pack_keys(d, ids))
+            gathered[r, q, :n] = keys
+    want = sharded.merge_keys_cpu(gathered, world, n_queries * k, n_queries, k, k)
+    ids, dist, cnt = _merge_on_gpu(gpu_ctx, gathered, world, n_queries * k, n_queries, k, k)
+    for q in range(n_queries):
+        w_ids, w_d = sharded.unpack_keys(want[q])
+        assert cnt[q] == w_ids.size
+        assert ids[q, : cnt[q]].tolist() == w_ids.tolist()
+        assert dist[q, : cnt[q]].tobytes() == w_d.tobytes()
+    assert cnt[-1] < k or k == 1
+
+
+@pytest.mark.parametrize("dtype_name", ["f32", "bin1"])
+def test_eight_shards_on_one_gpu_equal_the_single_store(gpu_ctx, dtype_name):
+    """Stores with docid_base = g * per play the eight ranks: vs_search_device on each, the keys laid
+    out as the all-gather would, one merge — against one store that holds everything."""
+    from search_engine_amd import abi, sharded
+    world, n, dim, k, n_q = 8, 1_250_000 if dtype_name == "bin1" else 200_000, 256 if dtype_name == "bin1" else 64, 10, 6
+    dtype, metric = (abi.VS_BIN1, abi.VS_HAMMING) if dtype_name == "bin1" else (abi.VS_F32, abi.VS_ANGULAR)
+    stream = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(7)
+    if dtype_name == "bin1":
+        rows = torch.randint(-(1 << 31), 1 << 31, (n, dim // 32), generator=gen, device=DEV, dtype=torch.int64).to(torch.int32)
+        queries = torch.randint(-(1 << 31), 1 << 31, (n_q, dim // 32), generator=gen, device=DEV, dtype=torch.int64).to(torch.int32)
+    else:
+        rows = torch.randn(n, dim, generator=gen, device=DEV)
+        queries = torch.randn(n_q, dim, generator=gen, device=DEV)
+    mask_np = facet_mask(-(-n // 64) * 64, 10)
+    d_mask = torch.from_numpy(mask_np.view(np.int64)).to(DEV)
+    whole = gpu_ctx.create_store(800, dim, n, dtype=dtype, metric=metric)
+    shards = []
+    try:
+        whole.upload_device(0, rows.data_ptr(), n, stream)
+        whole.seal()
+        ws = torch.empty(whole.workspace_bytes(k), dtype=torch.uint8, device=DEV)
+        want = torch.zeros(n_q * k, dtype=torch.int64, device=DEV)
+        for j in range(n_q):
+            whole.search_device(queries[j].data_ptr(), dim, k, d_mask.data_ptr(), ws.data_ptr(),
+                                want[j * k:].data_ptr(), stream)
+        gathered = torch.zeros(world * n_q * k, dtype=torch.int64, device=DEV)
+        for g in range(world):
+            first, count = sharded.shard_range(g, world, n)
+            st = gpu_ctx.create_store(801 + g, dim, max(count, 64), dtype=dtype, metric=metric, docid_base=first)
+            shards.append(st)
+            st.upload_device(first, rows[first:first + count].data_ptr(), count, stream)
+            st.seal()
+            for j in range(n_q):
+                st.search_device(queries[j].data_ptr(), dim, k, d_mask[first // 64:].data_ptr(), ws.data_ptr(),
+                                 gathered[(g * n_q + j) * k:].data_ptr(), stream)
+        torch.cuda.synchronize()
+        ids, dist, cnt = _merge_on_gpu(gpu_ctx, gathered.cpu().numpy(), world, n_q * k, n_q, k, k, metric)
+        want = want.cpu().numpy().view(np.uint64).reshape(n_q, k)
+        for j in range(n_q):
+            assert cnt[j] == k
+            assert ids[j].tolist() == (want[j] & np.uint64(0xFFFFFFFF)).astype(np.uint32).tolist()
+        # and the host restatement agrees with the kernel on real keys
+        cpu = sharded.merge_keys_cpu(gathered.cpu().numpy(), world, n_q * k, n_q, k, k)
+        assert cpu.tolist() == want.tolist()
+    finally:
+        whole.destroy()
+        for st in shards:
+            st.destroy()
+
+
+@pytest.mark.parametrize("flags_name", ["plain", "always_gather", "share_passes", "share_passes_gather"])
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16", "bin1"])
+def test_sharded_search_in_a_group_of_one(gpu_ctx, dtype_name, flags_name):
+    """vs_search_sharded_device, world 1: without the collective and (VS_SHARDED_ALWAYS_GATHER) through
+    a real one-rank RCCL all-gather; one scan per query and queries sharing passes."""
+    from search_engine_amd import abi
+    flags = {"plain": 0, "always_gather": abi.VS_SHARDED_ALWAYS_GATHER, "share_passes": abi.VS_SHARDED_SHARE_PASSES,
+             "share_passes_gather": abi.VS_SHARDED_SHARE_PASSES | abi.VS_SHARDED_ALWAYS_GATHER}[flags_name]
+    n, dim, k, n_q = 30_000, 128, 10, 9
+    dtype, metric = {"f32": (abi.VS_F32, abi.VS_ANGULAR), "bf16": (abi.VS_BF16, abi.VS_ANGULAR),
+                     "bin1": (abi.VS_BIN1, abi.VS_HAMMING)}[dtype_name]
+    rows = synthetic_vectors(n, dim, 71)
+    queries = synthetic_vectors(n_q, dim, 72)
+    mask = facet_mask(-(-n // 64) * 64, 50)
+    store = gpu_ctx.create_store(820, dim, n, dtype=dtype, metric=metric)
+    group = abi.Group(gpu_ctx, 0, 1, abi.group_unique_id())
+    try:
+        store.upload(np.arange(n, dtype=np.uint32), rows)
+        store.seal()
+        if dtype_name == "bin1":
+            packed = np.zeros((n_q, store.row_bytes // 8), np.uint64)
+            bits = np.packbits(queries > 0, axis=1, bitorder="little")
+            packed.view(np.uint8)[:, : bits.shape[1]] = bits
+            d_q = torch.from_numpy(packed.view(np.int64)).to(DEV)
+        else:
+            d_q = torch.from_numpy(queries).to(DEV)
+        d_mask = torch.from_numpy(mask.view(np.int64)).to(DEV)
+        ids = torch.zeros(n_q * k, dtype=torch.int32, device=DEV)
+        dist = torch.zeros(n_q * k, dtype=torch.float32, device=DEV)
+        cnt = torch.zeros(n_q, dtype=torch.int32, device=DEV)
+        stream = torch.cuda.current_stream().cuda_stream
+        for _ in range(2):  # the second call reuses the group's buffers
+            group.search_sharded_device(store, d_q.data_ptr(), n_q, dim, k, d_mask.data_ptr(), flags,
+                                        ids.data_ptr(), dist.data_ptr(), cnt.data_ptr(), stream)
+        torch.cuda.synchronize()
+        ids = ids.cpu().numpy().view(np.uint32).reshape(n_q, k)
+        dist = dist.cpu().numpy().reshape(n_q, k)
+        shares = flags & abi.VS_SHARDED_SHARE_PASSES
+        want = store.search_batch(queries, k, mask) if shares else [store.search(q, k, mask) for q in queries]
+        for j in range(n_q):
+            assert cnt[j].item() == k
+            assert ids[j].tolist() == want[j][0].tolist(), (j, flags_name)
+            assert dist[j].tobytes() == want[j][1].tobytes()
+    finally:
+        group.destroy()
+        store.destroy()

@@ -1,9 +1,9 @@
 """The multi-rank path (docid-range shards, one all-gather of top-k keys, merge) under
 torch.distributed with the gloo backend, world size 2 and 3, on the CPU. The
-shard-local scan and the final merge are stood in for by the CPU oracle and a
-numpy key sort; what is under test is the sharding arithmetic, the key format
-and the collective's layout ([rank][query][k]) — the same ShardedSearch object
-the GPU benchmark drives."""
+shard-local scan is stood in for by the CPU oracle and the final merge by the host
+restatement of the merge launch's layout contract (sharded.merge_keys_cpu, which
+tests/test_shard_merge_gpu.py pins to the kernel); what is under test is the sharding
+arithmetic, the key format and the collective's layout ([rank][query][k])."""
 import os
 import socket
 
@@ -43,11 +43,11 @@ def _worker(rank, world, port, n_docs, dim, k, batch, out_dir, all_at_once=False
             out_keys.copy_(torch.from_numpy(keys.view(np.int64)))
 
         def merge(gathered, w, n_q, kk):
-            g = gathered.numpy().view(np.uint64).reshape(w, batch, kk)
-            out = []
-            for q in range(n_q):
-                out.append(sharded.unpack_keys(np.sort(g[:, q, :].reshape(-1))[:kk]))
-            return out
+            # the merge launch's layout contract on the gathered [rank][query][k] buffer
+            # (list_stride = batch * k, query_stride = k); tests/test_shard_merge_gpu.py holds
+            # vs_merge_topk_batch_device to the same function
+            merged = sharded.merge_keys_cpu(gathered.numpy(), w, batch * kk, n_q, kk, kk)
+            return [sharded.unpack_keys(merged[q]) for q in range(n_q)]
 
         def local_search_all(n, keys):  # the batched form: every query of the step in one call
             for j in range(n):
