@@ -158,6 +158,42 @@ int32_t vs_store_contains(vs_store* s, uint32_t docid, int32_t* out);
  * (bf16 widened; bin1 as 0.0 / 1.0). VS_E_INVALID_ARG if the item is absent. */
 int32_t vs_store_item_vector(vs_store* s, uint32_t docid, float* out);
 
+/* arroy Writer::is_empty / the item count of the WRITER's view (uploads and
+ * removals since the last seal included), which the build loop tests before it
+ * builds a store (src/update/index_documents/mod.rs:559-561). */
+int32_t vs_store_writer_len(vs_store* s, uint64_t* n_items);
+
+/* ---- filling stores from the reference's vector database -------------------- */
+
+/* Takes `n` raw (key, value) pairs of the reference's `vector-arroy` LMDB
+ * database (src/index.rs:152-155,208) exactly as a cursor yields them, and
+ * uploads every ITEM LEAF into the store whose index is the key's
+ * `(embedder_id << 8) | k` (stores must have been created; the write path's
+ * "vectors packed in the first writers" layout, typed_chunk.rs:597-607, is
+ * thereby taken over as it is on disk). Tree nodes and metadata are skipped and
+ * counted in *n_other_nodes: the exhaustive scan needs no forest. Leaves of an
+ * index without a store are counted in *n_unrouted. A leaf whose dimension
+ * differs from its store's is VS_E_DIM_MISMATCH, anything malformed VS_E_FORMAT.
+ * Follow with vs_store_seal on the stores touched (arroy: build). arroy 0.2.0's
+ * node layout is restated from the published crate and unverified here (the
+ * crate is not in the reference tree):
+ *   key   = index u16 BE | mode u8 (0 item, 1 tree, 2 metadata) | item u32 BE
+ *   leaf  = tag u8 (0) | norm f32 | dim x f32 little endian
+ * Replaces the item reads of arroy::Reader::open / nns_by_vector
+ * (src/search/context.rs:188-190) for an index that already exists on disk. */
+int32_t vs_ingest_arroy_items(vs_ctx* ctx, const uint8_t* const* keys, const size_t* key_lens,
+                              const uint8_t* const* values, const size_t* value_lens, uint64_t n,
+                              uint64_t* n_items, uint64_t* n_other_nodes, uint64_t* n_unrouted);
+/* The key layout alone (mode: 0 item, 1 tree, 2 metadata). */
+int32_t vs_arroy_parse_key(const uint8_t* key, size_t len, uint16_t* index, uint8_t* mode,
+                           uint32_t* item);
+/* Writes the 7-byte key and the leaf bytes of one item in the layout above
+ * (value_out == NULL: only *value_len). For hosts and tests that have vectors
+ * but no arroy at hand. */
+int32_t vs_arroy_encode_item(uint16_t index, uint32_t item, const float* vector, uint32_t dim,
+                             uint8_t* key_out /* 7 bytes */, uint8_t* value_out, size_t value_cap,
+                             size_t* value_len);
+
 /* ---- search, host buffers ------------------------------------------------ */
 
 /* Replaces reader.nns_by_vector(txn, target, limit, None, Some(candidates))

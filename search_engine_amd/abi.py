@@ -52,6 +52,10 @@ SIGNATURES = {
     "vs_store_row_bytes": [_vp, _u64p],
     "vs_store_contains": [_vp, _u32, _i32p],
     "vs_store_item_vector": [_vp, _u32, _f32p],
+    "vs_store_writer_len": [_vp, _u64p],
+    "vs_ingest_arroy_items": [_vp, ctypes.POINTER(_u8p), _szp, ctypes.POINTER(_u8p), _szp, _u64, _u64p, _u64p, _u64p],
+    "vs_arroy_parse_key": [_u8p, _sz, ctypes.POINTER(_u16), _u8p, _u32p],
+    "vs_arroy_encode_item": [_u16, _u32, _f32p, _u32, _u8p, _u8p, _sz, _szp],
     "vs_search": [_vp, _f32p, _u32, _u32, _u64p, _u64, _u32p, _f32p, _u32p],
     "vs_search_roaring": [_vp, _f32p, _u32, _u32, _u8p, _sz, _u32p, _f32p, _u32p],
     "vs_search_batch": [_vp, _f32p, _u32, _u32, _u32, _u64p, _u64, _u32p, _f32p, _u32p],
@@ -171,6 +175,22 @@ class Context:
         _check(lib.vs_store_open(self.handle, index, ctypes.byref(h)), self.handle)
         return Store(self, h)
 
+    def ingest_arroy_items(self, pairs):
+        """pairs: iterable of (key bytes, value bytes) of the reference's vector-arroy database.
+        Returns (item leaves uploaded, other nodes skipped, leaves without a store)."""
+        pairs = list(pairs)
+        n = len(pairs)
+        keep = [(np.frombuffer(k, np.uint8), np.frombuffer(v, np.uint8) if len(v) else np.zeros(1, np.uint8))
+                for k, v in pairs]
+        keys = (_u8p * max(n, 1))(*[a.ctypes.data_as(_u8p) for a, _ in keep])
+        vals = (_u8p * max(n, 1))(*[b.ctypes.data_as(_u8p) for _, b in keep])
+        klen = (_sz * max(n, 1))(*[len(k) for k, _ in pairs])
+        vlen = (_sz * max(n, 1))(*[len(v) for _, v in pairs])
+        a, b, c = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
+        _check(lib.vs_ingest_arroy_items(self.handle, keys, klen, vals, vlen, n, ctypes.byref(a), ctypes.byref(b),
+                                         ctypes.byref(c)), self.handle)
+        return a.value, b.value, c.value
+
     def merge_topk_device(self, d_keys, n_lists, k, metric, d_ids, d_dist, d_n, stream=0):
         _check(lib.vs_merge_topk_device(self.handle, d_keys, n_lists, k, metric, d_ids, d_dist, d_n,
                                         stream), self.handle)
@@ -247,6 +267,11 @@ class Store:
     def __len__(self):
         n = ctypes.c_uint64(0)
         self._ck(lib.vs_store_len(self.handle, ctypes.byref(n)))
+        return n.value
+
+    def writer_len(self):
+        n = ctypes.c_uint64(0)
+        self._ck(lib.vs_store_writer_len(self.handle, ctypes.byref(n)))
         return n.value
 
     @property
@@ -380,6 +405,29 @@ class Store:
     def search_device_noalloc(self, d_query, dim, k, d_mask, d_out_keys, stream=0):
         """vs_search_device on the library's static scratch: no workspace, no allocation."""
         self._ck(lib.vs_search_device_noalloc(self.handle, d_query, dim, k, d_mask, d_out_keys, stream))
+
+
+# ---- arroy's on-disk item layout (host only) ---------------------------------------------
+
+
+def arroy_encode_item(index, item, vector):
+    """(key bytes, leaf bytes) of one item as the reference's vector-arroy database holds it."""
+    vector = np.ascontiguousarray(vector, np.float32)
+    key = np.zeros(7, np.uint8)
+    n = ctypes.c_size_t(0)
+    _check(lib.vs_arroy_encode_item(index, item, _ptr(vector, _f32p), vector.size, _ptr(key, _u8p), None, 0,
+                                    ctypes.byref(n)))
+    val = np.zeros(n.value, np.uint8)
+    _check(lib.vs_arroy_encode_item(index, item, _ptr(vector, _f32p), vector.size, _ptr(key, _u8p),
+                                    _ptr(val, _u8p), val.size, ctypes.byref(n)))
+    return key.tobytes(), val.tobytes()
+
+
+def arroy_parse_key(key):
+    keep, kp = _bytes_ptr(key)
+    index, mode, item = ctypes.c_uint16(0), ctypes.c_uint8(0), ctypes.c_uint32(0)
+    _check(lib.vs_arroy_parse_key(kp, len(key), ctypes.byref(index), ctypes.byref(mode), ctypes.byref(item)))
+    return index.value, mode.value, item.value
 
 
 # ---- candidate bitmap codecs (host only, no GPU needed) --------------------------------

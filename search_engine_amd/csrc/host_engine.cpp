@@ -808,4 +808,180 @@ std::pair<SearchResult, std::optional<uint32_t>> execute_hybrid(const HybridInpu
     return {std::move(merged.first), merged.second};
 }
 
+// ---- write path ------------------------------------------------------------------------------------------------
+
+std::map<std::string, uint8_t> assign_embedder_category_ids(const std::vector<std::string>& embedder_names) {
+    // new_configs is a BTreeMap<String, _>: iteration in byte-wise name order, duplicates collapse
+    std::map<std::string, uint8_t> ids;
+    for (const auto& name : embedder_names) ids.emplace(name, 0);
+    size_t index = 0;
+    for (auto& kv : ids) {
+        if (index > 0xFF)  // `index.try_into()` into u8 (settings.rs:781-783)
+            throw Error(Error::TooManyEmbedders, "Too many embedders in the configuration. Found " +
+                                                     std::to_string(ids.size()) + ", but limited to 256.");
+        kv.second = (uint8_t)index++;
+    }
+    return ids;
+}
+
+namespace {
+class GpuWriter : public Writer {
+   public:
+    GpuWriter(vs_ctx* ctx, uint16_t index, uint32_t dimension, uint64_t capacity)
+        : ctx_(ctx), index_(index), dimension_(dimension), capacity_(capacity) {}
+    ~GpuWriter() override = default;  // stores belong to the context
+
+    bool del_item(DocumentId docid) override {
+        if (!contains_item(docid)) return false;
+        check(vs_store_remove(store_, &docid, 1));
+        return true;
+    }
+    void add_item(DocumentId docid, const std::vector<float>& vector) override {
+        if (vector.size() != dimension_)
+            throw Error(Error::InvalidVectorDimensions,
+                        "Invalid vector dimensions: expected: `" + std::to_string(dimension_) + "`, found: `" +
+                            std::to_string(vector.size()) + "`.",
+                        dimension_, (uint32_t)vector.size());
+        if (!store_) {
+            // an index built by an earlier run already has its store
+            if (vs_store_open(ctx_, index_, &store_) != VS_OK) {
+                store_ = nullptr;
+                check(vs_store_create(ctx_, index_, dimension_, VS_F32, VS_ANGULAR, 0, capacity_, &store_));
+            }
+        }
+        if ((uint64_t)docid >= capacity_) {  // milli hands out ever larger docids
+            while ((uint64_t)docid >= capacity_) capacity_ *= 2;
+            check(vs_store_reserve(store_, capacity_));
+        }
+        check(vs_store_upload(store_, &docid, vector.data(), 1));
+    }
+    std::optional<std::vector<float>> item_vector(DocumentId docid) override {
+        if (!contains_item(docid)) return std::nullopt;
+        std::vector<float> out(dimension_);
+        check(vs_store_item_vector(store_, docid, out.data()));
+        return out;
+    }
+    bool contains_item(DocumentId docid) override {
+        if (!attach()) return false;
+        int32_t has = 0;
+        check(vs_store_contains(store_, docid, &has));
+        return has != 0;
+    }
+    bool is_empty() override {
+        if (!attach()) return true;
+        uint64_t n = 0;
+        check(vs_store_writer_len(store_, &n));
+        return n == 0;
+    }
+    void build() override {
+        if (attach()) check(vs_store_seal(store_));
+    }
+    // The reference does not rebuild a store whose last item was removed, and what arroy then
+    // answers from the stale tree over deleted leaves cannot be established here. A slab must
+    // not go on returning removed documents, so the emptied store is sealed.
+    void publish_if_emptied() override {
+        uint64_t sealed = 0;
+        if (attach() && vs_store_len(store_, &sealed) == VS_OK && sealed != 0) check(vs_store_seal(store_));
+    }
+
+   private:
+    bool attach() {
+        if (!store_ && vs_store_open(ctx_, index_, &store_) != VS_OK) store_ = nullptr;
+        return store_ != nullptr;
+    }
+    void check(int32_t rc) {
+        if (rc != VS_OK) throw Error(Error::ArroyError, last_error(ctx_));
+    }
+    vs_ctx* ctx_;
+    uint16_t index_;
+    uint32_t dimension_;
+    uint64_t capacity_;
+    vs_store* store_ = nullptr;
+};
+}  // namespace
+
+struct GpuWriters::Impl {
+    std::vector<std::unique_ptr<GpuWriter>> writers;
+};
+
+GpuWriters::GpuWriters(vs_ctx* ctx, uint8_t embedder_index, uint32_t dimension, uint64_t capacity)
+    : impl_(new Impl()) {
+    const uint16_t writer_index = (uint16_t)((uint16_t)embedder_index << 8);
+    for (uint32_t k = 0; k <= 0xFF; ++k)
+        impl_->writers.emplace_back(new GpuWriter(ctx, (uint16_t)(writer_index | k), dimension, capacity));
+}
+GpuWriters::~GpuWriters() = default;
+Writer& GpuWriters::writer(uint8_t k) { return *impl_->writers[k]; }
+
+void write_vector_points(Writers& writers, const VectorPoints& points) {
+    // remove vectors for docids we want them removed (typed_chunk.rs:610-622)
+    for (DocumentId docid : points.remove_vectors)
+        for (uint32_t k = 0; k <= 0xFF; ++k)
+            // uses invariant: vectors are packed in the first writers
+            if (!writers.writer((uint8_t)k).del_item(docid)) break;
+
+    // add generated embeddings (:624-652)
+    for (const auto& [docid, embeddings] : points.embeddings) {
+        if (embeddings.size() > 0xFF)
+            throw Error(Error::TooManyVectors, "Too many vectors for document with id " + std::to_string(docid) +
+                                                   ": found " + std::to_string(embeddings.size()) +
+                                                   ", but limited to 256.");
+        for (size_t k = 0; k < embeddings.size(); ++k) writers.writer((uint8_t)k).add_item(docid, embeddings[k]);
+    }
+
+    // perform the manual diff (:654-707)
+    for (const auto& diff : points.manual_vectors) {
+        const DocumentId docid = diff.docid;
+        if (diff.deletion) {
+            std::optional<uint32_t> deleted_index;
+            for (uint32_t index = 0; index <= 0xFF; ++index) {
+                Writer& writer = writers.writer((uint8_t)index);
+                const auto candidate = writer.item_vector(docid);
+                if (!candidate) break;  // packed in the first writers
+                if (*candidate == *diff.deletion) {
+                    writer.del_item(docid);
+                    deleted_index = index;
+                }
+            }
+            // enforce the invariant: the last vector of the document moves into the hole
+            if (deleted_index) {
+                std::optional<std::pair<uint32_t, std::vector<float>>> last_index_with_a_vector;
+                for (uint32_t index = *deleted_index; index <= 0xFF; ++index) {
+                    auto candidate = writers.writer((uint8_t)index).item_vector(docid);
+                    if (!candidate) break;
+                    last_index_with_a_vector = std::make_pair(index, std::move(*candidate));
+                }
+                if (last_index_with_a_vector) {
+                    writers.writer((uint8_t)last_index_with_a_vector->first).del_item(docid);
+                    writers.writer((uint8_t)*deleted_index).add_item(docid, last_index_with_a_vector->second);
+                }
+            }
+        }
+        if (diff.addition) {
+            // overflow was detected during vector extraction
+            for (uint32_t k = 0; k <= 0xFF; ++k) {
+                Writer& writer = writers.writer((uint8_t)k);
+                if (!writer.contains_item(docid)) {
+                    writer.add_item(docid, *diff.addition);
+                    break;
+                }
+            }
+        }
+    }
+}
+
+uint32_t build_vector_stores(Writers& writers) {
+    uint32_t built = 0;
+    for (uint32_t k = 0; k <= 0xFF; ++k) {
+        Writer& writer = writers.writer((uint8_t)k);
+        if (writer.is_empty()) {
+            writer.publish_if_emptied();
+            break;
+        }
+        writer.build();
+        ++built;
+    }
+    return built;
+}
+
 }  // namespace search_engine

@@ -14,6 +14,9 @@
 //   Context (vector methods)          src/search/context.rs:28,59,60
 //   execute_vector_search             src/search/search.rs:98-135
 //   hybrid merge                      src/search/hybrid.rs
+//   embedder category ids             src/update/settings.rs:775-785
+//   vector write path                 src/update/index_documents/typed_chunk.rs:562-710,
+//                                     src/update/index_documents/mod.rs:544-566
 #pragma once
 #include <stdint.h>
 
@@ -39,7 +42,9 @@ struct Error : std::runtime_error {
     enum Kind {
         InvalidEmbedder,          // UserError::InvalidEmbedder (context.rs:183-186)
         InvalidVectorDimensions,  // UserError::InvalidVectorDimensions (error.rs:262-264)
-        ArroyError                // InternalError::ArroyError (error.rs:266-272)
+        ArroyError,               // InternalError::ArroyError (error.rs:266-272)
+        TooManyVectors,           // UserError::TooManyVectors (typed_chunk.rs:644-647)
+        TooManyEmbedders          // UserError::TooManyEmbedders (update/settings.rs:783)
     };
     Kind kind;
     uint32_t expected = 0, found = 0;
@@ -296,5 +301,67 @@ struct HybridInput {
 // Search::execute_hybrid (hybrid.rs:138-199)
 std::pair<SearchResult, std::optional<uint32_t>> execute_hybrid(const HybridInput& in,
                                                                 float semantic_ratio);
+
+// ---- write path --------------------------------------------------------------------------------------------
+
+// The ids `update_embedding_configs` writes into `embedder_category_id` (update/settings.rs:775-785):
+// the database is cleared and the embedders that remain get 0, 1, 2, ... in BTreeMap (byte-wise
+// name) order. More than 256 embedders: Error::TooManyEmbedders.
+std::map<std::string, uint8_t> assign_embedder_category_ids(const std::vector<std::string>& embedder_names);
+
+// arroy::Writer<Angular> as the indexer uses it (typed_chunk.rs:601-606,618,650,668,673,691,702;
+// index_documents/mod.rs:558-562).
+struct Writer {
+    virtual ~Writer() = default;
+    virtual bool del_item(DocumentId docid) = 0;  // true if the item existed
+    virtual void add_item(DocumentId docid, const std::vector<float>& vector) = 0;
+    virtual std::optional<std::vector<float>> item_vector(DocumentId docid) = 0;
+    virtual bool contains_item(DocumentId docid) = 0;
+    virtual bool is_empty() = 0;
+    virtual void build() = 0;
+    // Called by the build loop for the first EMPTY writer, which the reference leaves unbuilt
+    // (index_documents/mod.rs:559-561). No counterpart in arroy. A writer over a store that would
+    // otherwise keep answering with the items of its last build publishes its emptiness here.
+    virtual void publish_if_emptied() {}
+};
+
+// The 256 writers `(embedder_index << 8) | k` of one embedder.
+struct Writers {
+    virtual ~Writers() = default;
+    virtual Writer& writer(uint8_t k) = 0;
+};
+
+// Writers over libvs_amd.so: add_item = vs_store_upload, del_item = vs_store_remove, build =
+// vs_store_seal. A store is created (room for `capacity` docids) when its first item arrives.
+class GpuWriters : public Writers {
+   public:
+    GpuWriters(vs_ctx* ctx, uint8_t embedder_index, uint32_t dimension, uint64_t capacity);
+    ~GpuWriters() override;
+    Writer& writer(uint8_t k) override;
+
+   private:
+    struct Impl;
+    std::unique_ptr<Impl> impl_;
+};
+
+// TypedChunk::VectorPoints after its chunks were merged (typed_chunk.rs:82-88, 566-589).
+struct VectorPoints {
+    std::vector<DocumentId> remove_vectors;
+    // generated embeddings: every vector of a document (Embeddings<f32>)
+    std::vector<std::pair<DocumentId, std::vector<std::vector<float>>>> embeddings;
+    // user-provided vectors as a diff, one entry per (document, vector)
+    struct ManualDiff {
+        DocumentId docid;
+        std::optional<std::vector<float>> deletion, addition;
+    };
+    std::vector<ManualDiff> manual_vectors;
+};
+// The VectorPoints arm of write_typed_chunk_into_index (typed_chunk.rs:562-710): removals,
+// generated embeddings, then the manual diff — all three keep the documents' vectors packed in
+// the first writers.
+void write_vector_points(Writers& writers, const VectorPoints& points);
+// The build loop that ends an indexing run (index_documents/mod.rs:554-563): writers 0.. are built
+// until the first empty one. Returns the number of writers built.
+uint32_t build_vector_stores(Writers& writers);
 
 }  // namespace search_engine

@@ -214,6 +214,52 @@ std::shared_ptr<Context> context_from_py(const py::object& o) {
     return std::make_shared<PyContext>(o);
 }
 
+// Writers whose 256 writers are Python objects (an in-memory fake of arroy::Writer for the CPU tests)
+struct PyWriter : Writer {
+    py::object impl;
+    explicit PyWriter(py::object o) : impl(std::move(o)) {}
+    bool del_item(DocumentId d) override { return impl.attr("del_item")(d).cast<bool>(); }
+    void add_item(DocumentId d, const std::vector<float>& v) override { impl.attr("add_item")(d, v); }
+    std::optional<std::vector<float>> item_vector(DocumentId d) override {
+        py::object r = impl.attr("item_vector")(d);
+        if (r.is_none()) return std::nullopt;
+        return r.cast<std::vector<float>>();
+    }
+    bool contains_item(DocumentId d) override { return impl.attr("contains_item")(d).cast<bool>(); }
+    bool is_empty() override { return impl.attr("is_empty")().cast<bool>(); }
+    void build() override { impl.attr("build")(); }
+};
+struct PyWriters : Writers {
+    py::object factory;  // factory(k) -> writer object
+    std::map<uint8_t, std::unique_ptr<PyWriter>> made;
+    explicit PyWriters(py::object f) : factory(std::move(f)) {}
+    Writer& writer(uint8_t k) override {
+        auto it = made.find(k);
+        if (it == made.end()) it = made.emplace(k, std::unique_ptr<PyWriter>(new PyWriter(factory(k)))).first;
+        return *it->second;
+    }
+};
+
+VectorPoints points_from_py(const py::dict& d) {
+    VectorPoints p;
+    if (d.contains("remove_vectors")) p.remove_vectors = d["remove_vectors"].cast<std::vector<DocumentId>>();
+    if (d.contains("embeddings"))
+        for (py::handle e : d["embeddings"]) {
+            auto t = e.cast<std::pair<DocumentId, std::vector<std::vector<float>>>>();
+            p.embeddings.push_back(std::move(t));
+        }
+    if (d.contains("manual_vectors"))
+        for (py::handle e : d["manual_vectors"]) {
+            py::tuple t = py::reinterpret_borrow<py::tuple>(e);  // (docid, deletion | None, addition | None)
+            VectorPoints::ManualDiff m;
+            m.docid = t[0].cast<DocumentId>();
+            if (!t[1].is_none()) m.deletion = t[1].cast<std::vector<float>>();
+            if (!t[2].is_none()) m.addition = t[2].cast<std::vector<float>>();
+            p.manual_vectors.push_back(std::move(m));
+        }
+    return p;
+}
+
 py::object bucket_to_py(const std::optional<RankingRuleOutput>& b) {
     if (!b) return py::none();
     py::dict d;
@@ -234,6 +280,8 @@ PYBIND11_MODULE(_host, m) {
         } catch (const Error& e) {
             const char* kind = e.kind == Error::InvalidEmbedder            ? "InvalidEmbedder"
                                : e.kind == Error::InvalidVectorDimensions ? "InvalidVectorDimensions"
+                               : e.kind == Error::TooManyVectors          ? "TooManyVectors"
+                               : e.kind == Error::TooManyEmbedders        ? "TooManyEmbedders"
                                                                           : "ArroyError";
             PyErr_SetObject(host_error.ptr(), py::make_tuple(e.what(), kind, e.expected, e.found).ptr());
         }
@@ -307,6 +355,24 @@ PYBIND11_MODULE(_host, m) {
             return std::make_shared<GpuContext>(reinterpret_cast<vs_ctx*>(ctx_handle), std::move(ids),
                                                 to_docset(docids));
         }));
+
+    m.def("assign_embedder_category_ids", &assign_embedder_category_ids);
+    py::class_<GpuWriters>(m, "GpuWriters")
+        .def(py::init([](uintptr_t ctx_handle, uint8_t embedder_index, uint32_t dimension, uint64_t capacity) {
+            return new GpuWriters(reinterpret_cast<vs_ctx*>(ctx_handle), embedder_index, dimension, capacity);
+        }));
+    // writers: a GpuWriters, or a Python callable k -> fake writer object
+    m.def("write_vector_points", [](py::object writers, const py::dict& points) {
+        const VectorPoints p = points_from_py(points);
+        if (py::isinstance<GpuWriters>(writers)) return write_vector_points(writers.cast<GpuWriters&>(), p);
+        PyWriters w(writers);
+        write_vector_points(w, p);
+    });
+    m.def("build_vector_stores", [](py::object writers) {
+        if (py::isinstance<GpuWriters>(writers)) return build_vector_stores(writers.cast<GpuWriters&>());
+        PyWriters w(writers);
+        return build_vector_stores(w);
+    });
 
     py::class_<VectorSortHolder>(m, "VectorSort")
         .def(py::init([](py::object ctx, std::vector<float> target, py::object vector_candidates,

@@ -1,0 +1,149 @@
+"""An index that already exists on disk, and the write path, on the GPU.
+
+The reference's commented scenario (src/update/index_documents/mod.rs:2599-2619: documents with
+2 / 1 / 3 user-provided vectors, query [0, 1, 2]) is replayed twice: from synthesized arroy item
+leaves through vs_ingest_arroy_items (the bytes a host reads from `vector-arroy` with a cursor,
+tree and metadata nodes mixed in), and through the write-path mirror over GpuWriters, followed by
+deletions and replacements. Expected answers: tests/golden/appendix_b.json (hand-derived)."""
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import synthetic_vectors
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "appendix_b.json")))
+DOCS = {0: [[0, 1, 2], [3, 4, 5]], 1: [[6, 7, 8]], 2: [[9, 10, 11], [12, 13, 14], [15, 16, 17]]}
+
+
+def _search(gpu_ctx, category, name, universe, limit=10):
+    from search_engine_amd import _host
+    ctx = _host.GpuContext(gpu_ctx.handle.value, {name: category}, [0, 1, 2])
+    return _host.execute_vector_search(ctx, GOLDEN["query"], universe, 0, limit, name, None)
+
+
+def _check_emission(got, want):
+    assert got["documents_ids"] == [e["docid"] for e in want]
+    for s, e in zip(got["document_scores"], want):
+        assert s[0]["similarity"] == pytest.approx(e["similarity"], abs=2e-6)
+
+
+def _destroy_stores(gpu_ctx, category, n=4):
+    for k in range(n):
+        try:
+            gpu_ctx.open_store((category << 8) | k).destroy()
+        except Exception:  # noqa: BLE001  (never sealed or never made)
+            pass
+
+
+def test_existing_index_from_arroy_leaves(gpu_ctx):
+    from search_engine_amd import abi
+    category = 7
+    pairs = []
+    for docid, vectors in DOCS.items():
+        for k, v in enumerate(vectors):  # the j-th vector of a document lives in index (category << 8) | j
+            pairs.append(abi.arroy_encode_item((category << 8) | k, docid, v))
+    # what else a cursor over the database yields: tree nodes, metadata, another embedder's items
+    tree_key = bytes([category, 0, 1, 0, 0, 0, 9])
+    meta_key = bytes([category, 0, 2, 0, 0, 0, 0])
+    pairs += [(tree_key, bytes([2]) + bytes(20)), (meta_key, b"\x03\x00\x00\x00angular")]
+    pairs.append(abi.arroy_encode_item((9 << 8) | 0, 1, [1, 1, 1]))
+    pairs.sort()  # LMDB order
+    stores = [gpu_ctx.create_store((category << 8) | k, 3, 64) for k in range(3)]
+    try:
+        assert gpu_ctx.ingest_arroy_items(pairs) == (6, 2, 1)
+        for s in stores:
+            s.seal()
+        assert [len(s) for s in stores] == [3, 2, 1]
+        for k, want in enumerate(GOLDEN["stores"]):
+            ids, dist = stores[k].search(np.array(GOLDEN["query"], np.float32), 10)
+            assert ids.tolist() == [e["docid"] for e in want]
+            assert dist == pytest.approx([e["distance"] for e in want], abs=1e-6)
+        _check_emission(_search(gpu_ctx, category, "manual", [0, 1, 2]), GOLDEN["emission"])
+        _check_emission(_search(gpu_ctx, category, "manual", [1, 2]), GOLDEN["emission_filtered_1_2"])
+        # a leaf of the wrong dimension, and bytes that are no leaf
+        key, leaf = abi.arroy_encode_item((category << 8) | 0, 5, [1, 2, 3, 4])
+        with pytest.raises(abi.VsError) as e:
+            gpu_ctx.ingest_arroy_items([(key, leaf)])
+        assert e.value.code == abi.VS_E_DIM_MISMATCH and (e.value.expected, e.value.received) == (3, 4)
+        with pytest.raises(abi.VsError) as e:
+            gpu_ctx.ingest_arroy_items([(key, bytes([1]) + leaf[1:])])
+        assert e.value.code == abi.VS_E_FORMAT
+        with pytest.raises(abi.VsError) as e:
+            gpu_ctx.ingest_arroy_items([(key[:6], leaf)])
+        assert e.value.code == abi.VS_E_FORMAT
+    finally:
+        for s in stores:
+            s.destroy()
+
+
+def test_bulk_ingest_equals_upload(gpu_ctx):
+    from search_engine_amd import abi
+    n, dim, index = 5000, 96, (11 << 8)
+    rows = synthetic_vectors(n, dim, 81)
+    docids = np.random.default_rng(82).permutation(20_000)[:n].astype(np.uint32)
+    a = gpu_ctx.create_store(index, dim, 20_000)
+    b = gpu_ctx.create_store(index | 1, dim, 20_000)
+    try:
+        assert gpu_ctx.ingest_arroy_items(abi.arroy_encode_item(index, int(d), r) for d, r in zip(docids, rows)) == (n, 0, 0)
+        a.seal()
+        b.upload(docids, rows)
+        b.seal()
+        q = synthetic_vectors(1, dim, 83)[0]
+        ra, rb = a.search(q, 50), b.search(q, 50)
+        assert ra[0].tolist() == rb[0].tolist() and ra[1].tobytes() == rb[1].tobytes()
+    finally:
+        a.destroy()
+        b.destroy()
+
+
+def test_write_path_over_gpu_stores(gpu_ctx):
+    """write_vector_points / build_vector_stores (typed_chunk.rs:562-710, index_documents/mod.rs:554-563)
+    driving vs_store_upload / remove / item_vector / seal."""
+    from search_engine_amd import _host
+    category = 12
+    writers = _host.GpuWriters(gpu_ctx.handle.value, category, 3, 64)
+    try:
+        for docid, vectors in DOCS.items():  # three add_documents calls, each ending in the build loop
+            _host.write_vector_points(writers, {"manual_vectors": [(docid, None, [float(x) for x in v]) for v in vectors]})
+            _host.build_vector_stores(writers)
+        _check_emission(_search(gpu_ctx, category, "manual", [0, 1, 2]), GOLDEN["emission"])
+        _check_emission(_search(gpu_ctx, category, "manual", [1, 2]), GOLDEN["emission_filtered_1_2"])
+        # document 0 loses [0,1,2]: its best vector is now [3,4,5] in store 1 (similarity 1 - 0.057281)
+        _host.write_vector_points(writers, {"manual_vectors": [(0, [0.0, 1.0, 2.0], None)]})
+        got = _search(gpu_ctx, category, "manual", [0, 1, 2])
+        assert got["documents_ids"] == [0, 1, 2]  # not sealed yet: searches see the last build
+        assert _host.build_vector_stores(writers) == 3
+        got = _search(gpu_ctx, category, "manual", [0, 1, 2])
+        assert got["documents_ids"] == [0, 1, 2]
+        assert got["document_scores"][0][0]["similarity"] == pytest.approx(1 - 0.05728112757642695, abs=2e-6)
+        # document 1 is replaced by a vector parallel to the query (distance 0): deletion + addition
+        _host.write_vector_points(writers, {"manual_vectors": [(1, [6.0, 7.0, 8.0], [0.0, 2.0, 4.0])]})
+        _host.build_vector_stores(writers)
+        got = _search(gpu_ctx, category, "manual", [0, 1, 2])
+        assert got["documents_ids"] == [1, 0, 2]
+        assert got["document_scores"][0][0]["similarity"] == pytest.approx(1.0, abs=2e-6)
+        # document 2 is deleted: remove_vectors walks the packed writers
+        _host.write_vector_points(writers, {"remove_vectors": [2]})
+        _host.build_vector_stores(writers)
+        got = _search(gpu_ctx, category, "manual", [0, 1, 2])
+        # (store 2 is now empty: the build loop stops there, and the emptied store stops answering)
+        assert got["documents_ids"][:2] == [1, 0]
+        assert len(got["documents_ids"]) == 2 or got["document_scores"][2][0]["similarity"] is None
+        # a vector of the wrong dimension is the reference's user error
+        with pytest.raises(_host.HostError) as e:
+            _host.write_vector_points(writers, {"manual_vectors": [(3, None, [1.0, 2.0])]})
+        assert e.value.args[1] == "InvalidVectorDimensions" and e.value.args[2:] == (3, 2)
+        # docids beyond the first capacity make the store grow
+        _host.write_vector_points(writers, {"manual_vectors": [(1000, None, [0.0, 1.0, 2.0])]})
+        _host.build_vector_stores(writers)
+        ctx = _host.GpuContext(gpu_ctx.handle.value, {"manual": category}, [0, 1, 1000])
+        got = _host.execute_vector_search(ctx, GOLDEN["query"], [0, 1, 1000], 0, 10, "manual", None)
+        assert got["documents_ids"] == [1, 1000, 0]
+    finally:
+        del writers
+        _destroy_stores(gpu_ctx, category)
