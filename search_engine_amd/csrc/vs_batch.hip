@@ -40,6 +40,8 @@
 // sample, and the rest of the store with it as the bound.
 #include "vs_kernels.h"
 
+#include <stdlib.h>
+
 #include "../../include/vs_abi.h"
 #include "vs_device.h"
 
@@ -96,6 +98,7 @@ struct BatchArgs {
     // scans the non-sample tiles among b, b + gridDim.x, ...
     uint32_t n_tiles, sample_stride, sample_count, pass;
     uint32_t lists;            // gridDim.x, + 1 when bound_keys is carried along as a list of its own
+    const uint32_t* gate;      // nullable: the launch does nothing unless *gate != 0 (the rare-case second pass)
 };
 
 // Byte offset of 16-byte slot `slot` (0..7) of row `row` in a [rows][64] bf16 image.
@@ -121,6 +124,7 @@ template <bool DMA, bool FIRST>
 __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) {
     constexpr int KMAX = DMA ? (int)DMA_MAX_K : (int)VS_BATCH_MAX_K;  // k <= KMAX in this build
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
+    if (a.gate && *a.gate == 0) return;  // wave-uniform
     unsigned char* const smem = lds_all + (DMA ? 2 : 1) * IMG_BYTES;  // the small arrays and the lists
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63, wv = uniform_u32(tid >> 6);
@@ -544,12 +548,465 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
     }
 }
 
+// ---- the streaming second pass ------------------------------------------------------------------
+//
+// The second pass does not need the generality of the kernel above: every query has a bound from
+// the sample, so almost no score survives; the bound does not tighten inside one workgroup's
+// 1/256 of the rows; and survivors can be judged later. Its K loop is the one above (64-element
+// steps, two 64 KiB images filled by LDS-DMA, one barrier per step); what goes is everything that
+// made the stream stand still between tiles:
+//  * no per-query lists in LDS, no owner threads, no drain: a survivor (score, query, row) goes to
+//    a small LDS queue, and wave 0 appends the PREVIOUS tile's queue to the workgroup's own region
+//    in global memory while the others multiply (it keeps the region's fill in a register: plain
+//    stores, no atomics). Later launches sort the regions into per-query buckets
+//    (batch_bucket_kernel), judge the buckets exactly and merge them with the sample's list
+//    (batch_select_kernel);
+//  * nothing in the loop returns a value from vector memory, so the compiler never waits for
+//    loads that are still wanted in flight: the next tile's norms arrive by LDS-DMA, tile ids and
+//    candidate words through the scalar cache (constant address space);
+//  * the tiles to visit (a candidate outside the sample) come as a list made by a tiny launch, so a
+//    workgroup always knows its next tile and the first steps of tile j + 1 are requested during
+//    the last steps of tile j without any test.
+// Anything the scheme cannot hold — a query without a bound or with a zero / non-finite norm, a
+// non-finite row norm, a full queue or region — raises `overflow`, and the launcher's gated rerun
+// of the general kernel produces the result instead.
+//
+// Tried and measured (10 M x 768, 256 queries; in-kernel stamps, cycles per 256-row tile): a ring
+// of 32-element sub-step images (6 document, 3 query buffers: 80 KiB of documents in flight across
+// barriers and tiles, counted vmcnt, raw barriers) ran its K loop in 40 k cycles, no better than the
+// 38.5 k of the plain loop, and at a lower clock (1.4 against 1.6 GHz); the same with the two
+// wave groups staggered by a phase (one reads and issues while the other multiplies) 50 k. With
+// the loads removed altogether the ring's loop took as long; with the MFMAs removed it still ran at
+// only 3.5 TB/s. A sub-step of 16 MFMAs per wave is too short to amortise its barrier, its LDS
+// latency and the 100-200 cycles each LDS-DMA instruction takes to issue.
+constexpr int S_OFF_NORM = 2 * IMG_BYTES;             // f32[2][256], by tile parity
+constexpr int S_OFF_QUEUE = S_OFF_NORM + 2 * BM * 4;  // u64[2][QCAP]
+constexpr int S_OFF_QCOUNT = S_OFF_QUEUE + 2 * QCAP * 8;
+constexpr int S_LDS = S_OFF_QCOUNT + 16;
+static_assert(S_LDS <= 160 * 1024, "LDS carve exceeds 160 KiB");
+constexpr uint32_t TILE_NONE = 0xFFFFFFFFu;
+
+struct StreamArgs {
+    const u32x4* rows;
+    const float* norms;
+    const uint64_t* present;
+    const uint64_t* cand;
+    const u32x4* qrows;          // [256][ksteps * 8] bf16 vectors, zero padded
+    const float* qnorm;          // [256]
+    const uint64_t* bound_keys;  // [n_q][k] the sample's lists
+    const uint32_t* tiles;       // tiles with a candidate outside the sample, any order
+    const uint32_t* tile_count;
+    u32x4* regions;              // [gridDim.x][cap]: {score bits, docid, query, 0}
+    uint32_t* region_count;      // [gridDim.x]
+    uint32_t* overflow;
+    uint64_t n_slots;
+    uint32_t row_vecs, ksteps, docid_base, k, n_q, cap;
+};
+
+// atomicAdd on an LDS word, written out: before the builtin's ds_add the compiler waits for every
+// outstanding vector-memory operation (an LDS-DMA might write the word), which would drain the
+// step in flight for every survivor. No DMA ever targets the queue's counters.
+__device__ __forceinline__ uint32_t lds_add_return(uint32_t* word, uint32_t v) {
+    const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)word;
+    uint32_t old;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(addr), "v"(v) : "memory");
+    return old;
+}
+
+typedef const __attribute__((address_space(4))) uint32_t* const_u32;
+typedef const __attribute__((address_space(4))) uint64_t* const_u64;
+
+__global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63, wv = uniform_u32(tid >> 6);
+    const uint32_t wm = wv >> 1, wn = wv & 1;
+    const uint32_t r32 = lane & 31, half = lane >> 5;
+    float* snorm = reinterpret_cast<float*>(lds + S_OFF_NORM);
+    uint64_t* queue = reinterpret_cast<uint64_t*>(lds + S_OFF_QUEUE);
+    uint32_t* qcount = reinterpret_cast<uint32_t*>(lds + S_OFF_QCOUNT);
+    const int k = (int)a.k;
+    const uint32_t KS = a.ksteps;
+
+    // This lane's four query columns: the dot-product threshold a row's score must reach to beat
+    // the query's bound (pq >= c2 * |row| is necessary for d < bound; the margin lets rounding only
+    // admit too many). Constant for the launch.
+    float c2v[4];
+    bool col_ok[4];
+    bool bad = false;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const uint32_t q = wn * 128 + (uint32_t)n * 32 + r32;
+        col_ok[n] = q < a.n_q;
+        c2v[n] = 3.0e38f;
+        if (col_ok[n]) {
+            const uint64_t tau = a.bound_keys[(uint64_t)q * k + (k - 1)];
+            const float qn = a.qnorm[q];
+            const float c = (1.0f - 2.0f * f32_from_orderable((uint32_t)(tau >> 32))) * qn - qn * 1e-6f;
+            if (tau == KEY_NONE || !(qn > 0.0f) || !(qn < __builtin_inff()) || !(c == c)) bad = true;
+            c2v[n] = c;
+        }
+    }
+    if (tid < 2) qcount[tid] = 0;
+    if (__syncthreads_or(bad)) {  // (no DMA is in flight yet: the plain barrier is fine)
+        if (tid == 0) *a.overflow = 1u;
+        return;
+    }
+
+    const_u32 tiles = (const_u32)(uintptr_t)a.tiles;
+    const_u64 present = (const_u64)(uintptr_t)a.present;
+    const_u64 cand = (const_u64)(uintptr_t)a.cand;
+    const uint32_t count = *(const_u32)(uintptr_t)a.tile_count;
+    const uint32_t G = gridDim.x, b = blockIdx.x;
+    const uint32_t n_mine = count > b ? (count - b + G - 1) / G : 0;
+    if (n_mine == 0) return;
+    auto tile_at = [&](uint32_t j) -> uint32_t { return j < n_mine ? tiles[b + j * G] : TILE_NONE; };
+    const uint64_t n_words = a.n_slots >> 6;
+    auto words_of = [&](uint32_t t, uint64_t (&w)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint64_t wi = 4 * (uint64_t)t + (uint64_t)i;
+            uint64_t x = 0;
+            if (t != TILE_NONE && wi < n_words) {
+                x = present[wi];
+                if (a.cand) x &= cand[wi];
+            }
+            w[i] = x;
+        }
+    };
+
+    // One K step of one tile = 64 KiB, laid out and fetched exactly as in the kernel above.
+    const uint32_t row_bytes = a.row_vecs * 16u;
+    const __amdgpu_buffer_rsrc_t qres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<u32x4*>(a.qrows), 0, (int)((uint32_t)BN * KS * 128u), 0x00020000);
+    auto doc_rsrc = [&](uint32_t t) {
+        const bool live = t != TILE_NONE;
+        return __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<u32x4*>(a.rows + (live ? (uint64_t)t * BM * a.row_vecs : 0)), 0,
+            live ? (int)((uint32_t)BM * row_bytes) : 0, 0x00020000);
+    };
+    const uint32_t dslot[2] = {(lane & 7) ^ (lane >> 4), (lane & 7) ^ (4 + (lane >> 4))};
+    const uint32_t dva[2] = {(lane >> 3) * row_bytes + dslot[0] * 16u, (lane >> 3) * row_bytes + dslot[1] * 16u};
+    const uint32_t dvb[2] = {(lane >> 3) * (KS * 128u) + dslot[0] * 16u, (lane >> 3) * (KS * 128u) + dslot[1] * 16u};
+    // A wave's eight pieces of a step go out one by one, spread over the step (documents first, they
+    // have furthest to come; then queries): 64 pieces issued by all waves at
+    // once queue up behind the CU's one load path (16 cycles a piece), and the waves stand in that
+    // queue with the matrix pipe idle.
+    auto load_piece = [&](uint32_t t, uint32_t ks, uint32_t image, int pc) {  // pc 0..3: documents, 4..7: queries
+        unsigned char* img = lds + image * IMG_BYTES + wv * 4096;
+        if (pc < 4) {
+            const int i = pc;
+            const __amdgpu_buffer_rsrc_t ares = doc_rsrc(t);
+            const uint32_t kill = ks * 8 + dslot[i & 1] < a.row_vecs ? 0u : 0x40000000u;
+            // nt: every document byte is read once per launch
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ares, (lds_ptr)(img + i * 1024), 16, (int)(dva[i & 1] | kill),
+                                                     (int)(ks * 128u + (wv * 4 + i) * 8u * row_bytes), 0, 2);
+        } else {
+            const int i = pc - 4;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(qres, (lds_ptr)(img + IMG_B + i * 1024), 16, (int)dvb[i & 1],
+                                                     (int)(ks * 128u + (wv * 4 + i) * 8u * (KS * 128u)), 0, 0);
+        }
+    };
+    auto load_step = [&](uint32_t t, uint32_t ks, uint32_t image) {
+#pragma unroll
+        for (int pc = 0; pc < 8; ++pc) load_piece(t, ks, image, pc);
+    };
+    // the norms of tile t's rows into snorm[par] (one wave; rows past the end read 0)
+    auto issue_norms = [&](uint32_t t, uint32_t par) {
+        const bool live = t != TILE_NONE;
+        const uint64_t row0 = live ? (uint64_t)t * BM : 0;
+        const uint64_t left = live && a.n_slots > row0 ? a.n_slots - row0 : 0;
+        const __amdgpu_buffer_rsrc_t nres = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.norms + row0), 0, (int)((left < (uint64_t)BM ? left : (uint64_t)BM) * 4), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(nres, (lds_ptr)(lds + S_OFF_NORM + par * BM * 4 + i * 256), 4,
+                                                     (int)(lane * 4u), i * 256, 0, 0);
+    };
+
+    uint32_t t0 = tile_at(0), t1 = tile_at(1);
+    uint64_t w0[4];
+    words_of(t0, w0);
+    if (wv == 7) issue_norms(t0, 0);
+    uint32_t image = 0;  // the image the step about to be multiplied lands in
+    load_step(t0, 0, image);
+
+    const uint32_t frag_a = swz(wm * 64 + r32, half), frag_b = IMG_B + swz(wn * 128 + r32, half);
+    uint32_t t_prev = TILE_NONE;
+
+    // appends the queue of tile `t` (parity pp) to this workgroup's region; wave 0 only, which
+    // keeps the region's fill in `n_out`
+    uint32_t n_out = 0;
+    u32x4* const region = a.regions + (uint64_t)b * a.cap;
+    auto flush = [&](uint32_t t, uint32_t pp) {
+        uint32_t n = uniform_u32(qcount[pp]);
+        if (n > (uint32_t)QCAP || n_out + n > a.cap) {
+            if (lane == 0) *a.overflow = 1u;
+            n = 0;
+        }
+        for (uint32_t i = lane; i < n; i += 64) {
+            const uint64_t e = queue[pp * QCAP + i];
+            u32x4 out;
+            out[0] = (uint32_t)(e >> 32);
+            out[1] = a.docid_base + t * (uint32_t)BM + ((uint32_t)e & 0xFFu);
+            out[2] = ((uint32_t)e >> 8) & 0xFFu;
+            out[3] = 0;
+            region[n_out + i] = out;
+        }
+        n_out += n;
+        if (lane == 0) qcount[pp] = 0;
+    };
+
+    for (uint32_t j = 0; j < n_mine; ++j) {
+        const uint32_t par = j & 1;
+        // tile ids two ahead and the next tile's words are requested now and used a tile later
+        const uint32_t t2 = tile_at(j + 2);
+        uint64_t w1[4];
+        words_of(t1, w1);
+
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
+
+        for (uint32_t ks = 0; ks < KS; ++ks) {
+            // my pieces of this step are in LDS ...
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // ... everyone's are; the previous step's readers are done with the other image
+            __builtin_amdgcn_s_barrier();
+            if (ks == 0) {
+                if (tid < (uint32_t)BM) {
+                    // rows that are not candidates get a NaN norm: their t is NaN, which the running
+                    // maximum ignores
+                    const bool is_cand = (w0[tid >> 6] >> (tid & 63)) & 1;  // w0[] index is wave-uniform
+                    const float pn = snorm[par * BM + tid];
+                    if (is_cand && !(pn < __builtin_inff())) *a.overflow = 1u;
+                    if (!is_cand) snorm[par * BM + tid] = __builtin_nanf("");
+                }
+                if (wv == 0 && j > 0) flush(t_prev, par ^ 1u);
+                if (wv == 7) issue_norms(t1, par ^ 1u);
+            }
+            const unsigned char* img = lds + image * IMG_BYTES;
+            image ^= 1u;
+            const bool last = ks + 1 == KS;
+            const uint32_t nt = last ? t1 : t0, nks = last ? 0 : ks + 1;  // (past the last tile: zeros)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                uint32_t fo_a = frag_a ^ ((uint32_t)kk << 5), fo_b = frag_b ^ ((uint32_t)kk << 5);
+                asm volatile("" : "+v"(fo_a), "+v"(fo_b));  // recompute per step, do not keep 8 addresses live
+                bf16x8 fa[2], fb[4];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    fa[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + m * 32 * 128 + fo_a));
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    fb[n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + n * 32 * 128 + fo_b));
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    load_piece(nt, nks, image, kk * 2 + m);
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- register test: t = score - |row| * c2[query]; per query column the largest t.
+        // accumulator element e of MFMA tile (m, n) is row m*32 + (e&3) + 8*(e>>2) + 4*half,
+        // column n*32 + r32 of the wave tile
+        {
+            const float* norm_mine = snorm + par * BM + wm * 64 + 4 * half;
+            float tmax[2][4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) tmax[0][n] = tmax[1][n] = -__builtin_inff();
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4v pn4 = *reinterpret_cast<const f32x4v*>(norm_mine + m * 32 + 8 * g);
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                        for (int n = 0; n < 4; ++n)
+                            tmax[m][n] = __builtin_fmaxf(tmax[m][n], __builtin_fmaf(-pn4[jj], c2v[n], acc[m][n][g * 4 + jj]));
+                }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const bool lane_hit = tmax[m][n] >= 0.0f && col_ok[n];
+                    if (__ballot(lane_hit) == 0) continue;  // wave-uniform, the common case
+                    uint32_t hit = 0;
+                    if (lane_hit) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const float t = __builtin_fmaf(-norm_mine[m * 32 + (e & 3) + 8 * (e >> 2)], c2v[n], acc[m][n][e]);
+                            hit |= (t >= 0.0f) ? (1u << e) : 0u;
+                        }
+                    }
+                    while (hit) {
+                        const uint32_t e = (uint32_t)__builtin_ctz(hit);
+                        hit &= hit - 1;
+                        float v = acc[m][n][0];
+#pragma unroll
+                        for (int jj = 1; jj < 16; ++jj) v = (e == (uint32_t)jj) ? acc[m][n][jj] : v;
+                        const uint32_t wrow = (uint32_t)m * 32 + (e & 3) + 8u * (e >> 2) + 4u * half;
+                        const uint32_t idx = lds_add_return(qcount + par, 1u);
+                        if (idx < (uint32_t)QCAP)
+                            queue[par * QCAP + idx] = ((uint64_t)__float_as_uint(v) << 32) |
+                                                      ((wn * 128 + (uint32_t)n * 32 + r32) << 8) | (wm * 64 + wrow);
+                    }
+                }
+        }
+        t_prev = t0;
+        t0 = t1;
+        t1 = t2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w0[i] = w1[i];
+    }
+    // the last tile's survivors, once every wave has tested its scores
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wv == 0) {
+        flush(t_prev, (n_mine - 1) & 1u);
+        if (lane == 0) a.region_count[b] = n_out;
+    }
+}
+
+// The tiles the streaming pass has to visit: every tile outside the sample with at least one
+// candidate. One thread per tile, one atomic per wave; the order of the list does not matter.
+__global__ __launch_bounds__(256) void batch_tiles_kernel(const uint64_t* present, const uint64_t* cand,
+                                                          uint64_t n_words, uint32_t n_tiles, uint32_t sample_stride,
+                                                          uint32_t sample_count, uint32_t* tiles, uint32_t* tile_count) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    bool keep = false;
+    if (t < n_tiles && !(t % sample_stride == 0 && t / sample_stride < sample_count)) {
+        uint64_t any = 0;
+        for (int i = 0; i < 4; ++i) {
+            const uint64_t wi = 4 * (uint64_t)t + (uint64_t)i;
+            if (wi < n_words) any |= cand ? (present[wi] & cand[wi]) : present[wi];
+        }
+        keep = any != 0;
+    }
+    const uint64_t m = __ballot(keep);
+    if (m == 0) return;
+    uint32_t base = 0;
+    if (lane == __builtin_ctzll(m)) base = atomicAdd(tile_count, (uint32_t)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
+    if (keep) tiles[base + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = t;
+}
+
+// Sorts the workgroups' survivor regions into per-query buckets: one workgroup per region. The
+// region is counted per query in LDS first, so that a bucket's fill is bumped once per workgroup
+// and query instead of once per survivor (256 workgroups hammering 256 counters took 190 us).
+__global__ __launch_bounds__(256) void batch_bucket_kernel(const u32x4* regions, const uint32_t* region_count,
+                                                           uint32_t cap, uint64_t* buckets, uint32_t* bucket_count,
+                                                           uint32_t* overflow) {
+    __shared__ uint32_t cnt[BN], base[BN];
+    uint32_t n = region_count[blockIdx.x];
+    if (n > cap) n = cap;
+    const u32x4* mine = regions + (uint64_t)blockIdx.x * cap;
+    cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 256) atomicAdd(&cnt[mine[i][2] & 0xFFu], 1u);
+    __syncthreads();
+    {
+        const uint32_t c = cnt[threadIdx.x];
+        base[threadIdx.x] = c ? atomicAdd(bucket_count + threadIdx.x, c) : 0;
+        cnt[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const u32x4 e = mine[i];
+        const uint32_t q = e[2] & 0xFFu;
+        const uint32_t idx = base[q] + atomicAdd(&cnt[q], 1u);
+        if (idx < cap)
+            buckets[(uint64_t)q * cap + idx] = ((uint64_t)e[0] << 32) | e[1];
+        else
+            *overflow = 1u;
+    }
+}
+
+// Judges the survivors of the streaming pass exactly (arroy's formula on the score, the row's norm
+// and the query's norm) and merges them with the sample's list: one workgroup per query.
+__global__ __launch_bounds__(256) void batch_select_kernel(const uint64_t* buckets, const uint32_t* bucket_count,
+                                                           uint32_t cap, const uint64_t* sample, const float* norms,
+                                                           const float* qnorm, uint32_t docid_base, uint32_t k_,
+                                                           uint64_t* out_keys, uint32_t* out_ids, float* out_dist,
+                                                           uint32_t* out_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t q = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wv = uniform_u32(threadIdx.x >> 6);
+    const int k = (int)k_;
+    uint32_t n = bucket_count[q];
+    if (n > cap) n = cap;
+    const float qn = qnorm[q];
+    const uint64_t* mine = buckets + (uint64_t)q * cap;
+    WaveTopK top;
+    top.init(reinterpret_cast<uint64_t*>(smem) + (size_t)wv * k, k, lane);
+    auto offer = [&](uint64_t key) {
+        uint64_t m = __ballot(key < top.tau);
+        while (m) {
+            const int src = __builtin_ctzll(m);
+            top.insert(readlane_u64(key, src));
+            m &= m - 1;
+            m &= __ballot(key < top.tau);
+        }
+    };
+    for (uint32_t base = wv * 64; base < n; base += 256) {
+        const uint32_t i = base + (uint32_t)lane;
+        uint64_t key = KEY_NONE;
+        if (i < n) {
+            const uint64_t e = mine[i];
+            const uint32_t docid = (uint32_t)e;
+            const float v = __uint_as_float((uint32_t)(e >> 32));
+            const float pnqn = norms[docid - docid_base] * qn;
+            float d = 0.0f;
+            if (pnqn != 0.0f) d = (1.0f - v / pnqn) / 2.0f;
+            key = make_key(f32_orderable(d), docid);
+        }
+        offer(key);
+    }
+    if (wv == 0)  // the sample's rows are not among the streamed ones: its list joins as it is
+        for (int base = 0; base < k; base += 64)
+            offer(base + lane < k ? sample[(uint64_t)q * k + base + lane] : KEY_NONE);
+    top.spill();
+    __syncthreads();
+    if (wv == 0) {
+        for (int v = 1; v < 4; ++v) top.absorb(reinterpret_cast<uint64_t*>(smem) + (size_t)v * k);
+        uint32_t cnt = 0;
+        for (int base = 0; base < k; base += 64) {
+            const int i = base + lane;
+            const uint64_t key = top.at_lane(base);
+            if (i < k) {
+                if (out_keys) out_keys[(uint64_t)q * k + i] = key;
+                if (out_ids) {
+                    out_ids[(uint64_t)q * k + i] = (uint32_t)key;
+                    out_dist[(uint64_t)q * k + i] = key != KEY_NONE ? f32_from_orderable((uint32_t)(key >> 32)) : 0.0f;
+                }
+            }
+            cnt += (uint32_t)__popcll(__ballot(key != KEY_NONE));
+        }
+        if (out_n && lane == 0) out_n[q] = cnt;
+    }
+}
+
 // queries f32 [n_q][dim] -> bf16 rows [256][kvecs * 8] (round to nearest even, zero
 // padded) and the norm of each ROUNDED query; one wave per query row
 __global__ __launch_bounds__(256) void prep_queries_bf16_kernel(const float* queries, uint32_t n_q,
                                                                 uint32_t dim, uint32_t kelems,
-                                                                uint16_t* qrows, float* qnorm) {
+                                                                uint16_t* qrows, float* qnorm,
+                                                                uint32_t* counters, uint32_t n_counters) {
     const int lane = threadIdx.x & 63;
+    // the streaming pass's counters (tile count, overflow flag, bucket fill) start at zero
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_counters; i += gridDim.x * 256) counters[i] = 0;
     const uint32_t j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= (uint32_t)BN) return;
     float acc = 0.0f;
@@ -571,9 +1028,12 @@ __global__ __launch_bounds__(256) void prep_queries_bf16_kernel(const float* que
 namespace {
 
 struct BatchPlan {
-    uint32_t ksteps, n_tiles, sample_tiles, sample_stride, blocks1, blocks2;
-    size_t off_qnorm, off_sample, off_partial1, off_partial2, total;
+    uint32_t ksteps, n_tiles, sample_tiles, sample_stride, blocks1, blocks2, cap;
+    size_t off_qnorm, off_sample, off_partial1, off_partial2, off_counters, off_tiles, off_buckets, off_regions, total;
 };
+// counters: [0] tile count, [1] overflow flag, [2 .. 2 + 256) bucket fill, [258 .. 258 + 256) region fill
+constexpr uint32_t STREAM_GRID = 256;
+constexpr uint32_t N_COUNTERS = 2 + BN + STREAM_GRID;
 
 BatchPlan plan_batch(const SlabView& s, uint32_t k) {
     BatchPlan p;
@@ -598,6 +1058,22 @@ BatchPlan plan_batch(const SlabView& s, uint32_t k) {
     off += (size_t)BN * p.blocks1 * k * 8;
     p.off_partial2 = off;
     off += (size_t)BN * (p.blocks2 + 1) * k * 8;
+    // streaming second pass: a query expects k * rows / sample rows survivors (its bound is the k-th
+    // best of the sample); buckets hold four times that, a power of two between 1024 and 65536
+    const uint64_t sample_rows = (uint64_t)p.sample_tiles * BM;
+    const uint64_t expect = sample_rows ? (uint64_t)k * s.n_slots / sample_rows : 0;
+    uint32_t cap = 1024;
+    while (cap < 65536 && cap < 4 * expect) cap *= 2;
+    p.cap = cap;
+    off = (off + 255) / 256 * 256;
+    p.off_counters = off;
+    off += (size_t)N_COUNTERS * 4 + 256;
+    p.off_tiles = off;
+    off += ((size_t)p.n_tiles * 4 + 255) / 256 * 256;
+    p.off_buckets = off;
+    off += (size_t)BN * cap * 8;
+    p.off_regions = off;  // a workgroup's share of the survivors is a query's share: the same capacity
+    off += (size_t)STREAM_GRID * cap * 16;
     p.total = off + 256;
     return p;
 }
@@ -620,8 +1096,12 @@ hipError_t launch_scan_batch_bf16(const SlabView& s, const float* d_queries, uin
     uint64_t* sample = reinterpret_cast<uint64_t*>(ws + p.off_sample);
     uint64_t* partial1 = reinterpret_cast<uint64_t*>(ws + p.off_partial1);
     uint64_t* partial2 = reinterpret_cast<uint64_t*>(ws + p.off_partial2);
+    uint32_t* counters = reinterpret_cast<uint32_t*>(ws + p.off_counters);
+    uint32_t* tiles = reinterpret_cast<uint32_t*>(ws + p.off_tiles);
+    uint64_t* buckets = reinterpret_cast<uint64_t*>(ws + p.off_buckets);
+    u32x4* regions = reinterpret_cast<u32x4*>(ws + p.off_regions);
     hipLaunchKernelGGL(prep_queries_bf16_kernel, dim3(BN / 4), dim3(256), 0, stream, d_queries, n_q, s.dim,
-                       p.ksteps * BK, qrows, qnorm);
+                       p.ksteps * BK, qrows, qnorm, counters, N_COUNTERS);
     const bool dma = k <= DMA_MAX_K;
     const size_t lds = batch_lds_bytes(dma, k);
     // (k > 12: a register list would spill; the general build serves both passes)
@@ -645,6 +1125,7 @@ hipError_t launch_scan_batch_bf16(const SlabView& s, const float* d_queries, uin
     a.docid_base = s.docid_base;
     a.k = k;
     a.n_q = n_q;
+    a.gate = nullptr;
 
     // pass 1: the first tiles, no bound
     const bool two = p.blocks2 > 0;
@@ -664,7 +1145,46 @@ hipError_t launch_scan_batch_bf16(const SlabView& s, const float* d_queries, uin
     e = launch_merge_batch(partial1, p.blocks1, k, 1, n_q, (uint64_t)p.blocks1 * k, k, VS_ANGULAR, sample, nullptr,
                            nullptr, nullptr, stream);
     if (e != hipSuccess) return e;
-    // pass 2: everything else, bounded by the sample's k-th best
+    // pass 2: everything else, bounded by the sample's k-th best. The streaming kernel first ...
+    static const bool use_stream = getenv("VS_BATCH_NO_STREAM") == nullptr;  // measurement switch
+    if (use_stream) {
+        StreamArgs sa;
+        void (*stream_kernel)(StreamArgs) = scan_batch_stream_kernel;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(stream_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(batch_tiles_kernel, dim3((p.n_tiles + 255) / 256), dim3(256), 0, stream, s.present, cand,
+                           s.n_slots >> 6, p.n_tiles, p.sample_stride, p.sample_tiles, tiles, counters);
+        sa.rows = a.rows;
+        sa.norms = s.norms;
+        sa.present = s.present;
+        sa.cand = cand;
+        sa.qrows = a.qrows;
+        sa.qnorm = qnorm;
+        sa.bound_keys = sample;
+        sa.tiles = tiles;
+        sa.tile_count = counters;
+        sa.regions = regions;
+        sa.region_count = counters + 2 + BN;
+        sa.overflow = counters + 1;
+        sa.n_slots = s.n_slots;
+        sa.row_vecs = s.row_vecs;
+        sa.ksteps = p.ksteps;
+        sa.docid_base = s.docid_base;
+        sa.k = k;
+        sa.n_q = n_q;
+        sa.cap = p.cap;
+        hipLaunchKernelGGL(stream_kernel, dim3(STREAM_GRID), dim3(BTHREADS), S_LDS, stream, sa);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(batch_bucket_kernel, dim3(STREAM_GRID), dim3(256), 0, stream, regions, counters + 2 + BN,
+                           p.cap, buckets, counters + 2, counters + 1);
+        hipLaunchKernelGGL(batch_select_kernel, dim3(n_q), dim3(256), (size_t)4 * k * 8, stream, buckets, counters + 2,
+                           p.cap, sample, s.norms, qnorm, s.docid_base, k, out_keys, out_ids, out_dist, out_n);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        a.gate = counters + 1;  // ... and the general kernel only where it raised `overflow`
+    }
     a.bound_keys = sample;
     a.partial = partial2;
     a.pass = 2;
@@ -673,7 +1193,7 @@ hipError_t launch_scan_batch_bf16(const SlabView& s, const float* d_queries, uin
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     return launch_merge_batch(partial2, p.blocks2 + 1, k, 1, n_q, (uint64_t)(p.blocks2 + 1) * k, k, VS_ANGULAR,
-                              out_keys, out_ids, out_dist, out_n, stream);
+                              out_keys, out_ids, out_dist, out_n, stream, a.gate);
 }
 
 }  // namespace vs

@@ -135,7 +135,8 @@ hipError_t launch_merge(const uint64_t* keys, uint32_t n_lists, uint64_t list_st
 hipError_t launch_merge_batch(const uint64_t* keys, uint32_t n_lists, uint64_t list_stride,
                               uint64_t rank_stride, uint32_t n_queries, uint64_t query_stride,
                               uint32_t k, int32_t metric, uint64_t* out_keys, uint32_t* out_ids,
-                              float* out_dist, uint32_t* out_n, hipStream_t stream);
+                              float* out_dist, uint32_t* out_n, hipStream_t stream,
+                              const uint32_t* gate = nullptr);  // non-null: the launch does nothing unless *gate != 0
 
 // Expand a serialised RoaringBitmap already in device memory into the dense
 // mask `words[n_words]` covering docids [docid_base, docid_base + 64 n_words).

@@ -1167,8 +1167,9 @@ __global__ __launch_bounds__(256) void merge_kernel(const uint64_t* keys, uint32
                                                     uint32_t n_ranks, uint64_t query_stride,
                                                     uint32_t k_, int32_t metric, uint64_t* out_keys,
                                                     uint32_t* out_ids, float* out_dist,
-                                                    uint32_t* out_n) {
+                                                    uint32_t* out_n, const uint32_t* gate) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (gate && *gate == 0) return;  // a launch queued for the rare case only (nullable)
     keys += (uint64_t)blockIdx.x * query_stride;
     if (out_keys) out_keys += (uint64_t)blockIdx.x * k_;
     if (out_ids) {
@@ -1721,7 +1722,7 @@ hipError_t launch_merge(const uint64_t* keys, uint32_t n_lists, uint64_t list_st
 hipError_t launch_merge_batch(const uint64_t* keys, uint32_t n_lists, uint64_t list_stride,
                               uint64_t rank_stride, uint32_t n_queries, uint64_t query_stride,
                               uint32_t k, int32_t metric, uint64_t* out_keys, uint32_t* out_ids,
-                              float* out_dist, uint32_t* out_n, hipStream_t stream) {
+                              float* out_dist, uint32_t* out_n, hipStream_t stream, const uint32_t* gate) {
     if (k == 0 || k > VS_MAX_K || n_lists == 0 || n_queries == 0) return hipErrorInvalidValue;
     uint32_t n_ranks = k;
     // Few keys in one contiguous run (lists back to back, or the rank-major
@@ -1737,7 +1738,7 @@ hipError_t launch_merge_batch(const uint64_t* keys, uint32_t n_lists, uint64_t l
     }
     hipLaunchKernelGGL(merge_kernel, dim3(n_queries), dim3(256), (size_t)4 * k * 8, stream, keys,
                        n_lists, list_stride, rank_stride, n_ranks, query_stride, k, metric, out_keys,
-                       out_ids, out_dist, out_n);
+                       out_ids, out_dist, out_n, gate);
     return hipGetLastError();
 }
 

@@ -88,12 +88,16 @@ def test_batch_parity_filters_and_holes(gpu_ctx, pass_percent):
         store.destroy()
 
 
+@pytest.mark.parametrize("awkward", [True, False])
 @pytest.mark.parametrize("pass_percent,k", [(None, 10), (3, 10), (50, 32), ("top third", 10)])
-def test_batch_parity_beyond_the_sample_pass(gpu_ctx, pass_percent, k):
+def test_batch_parity_beyond_the_sample_pass(gpu_ctx, pass_percent, k, awkward):
     """More than 3 x 256 tiles of 256 rows: 256 tiles spread over the store (every third) are
-    scanned without a bound, the rest against the k-th best of that sample (register test,
-    survivor queue). The best rows are planted all over the store so that every path has to
-    deliver; one filter selects the top third of the docids only."""
+    scanned without a bound, the rest against the k-th best of that sample. The best rows are
+    planted all over the store so that every path has to deliver; one filter selects the top
+    third of the docids only. awkward = False: the streaming second pass delivers (survivors
+    through the queue, the regions, the buckets, the exact judgement). awkward = True: a zero
+    query and non-finite rows make that pass give up, and the gated rerun of the general kernel
+    (register test, owner threads, chunked walk) delivers instead."""
     n, dim = 256 * 256 * 3 + 64 * 3, 64
     vectors = synthetic_vectors(n, dim, 0x7A11)
     queries = synthetic_vectors(37, dim, 0x7A12)
@@ -103,9 +107,10 @@ def test_batch_parity_beyond_the_sample_pass(gpu_ctx, pass_percent, k):
             vectors[pos] = queries[j] * (1.0 + 0.01 * rng.standard_normal()) + 0.05 * rng.standard_normal(dim).astype(np.float32)
     vectors[n - 1] = queries[0]
     vectors[70000] = 0.0          # zero-norm row in the bounded pass
-    vectors[100000, 0] = np.inf   # non-finite rows: their tile takes the chunked walk; NaN distances sort last
-    vectors[100300, 3] = np.nan
-    queries[5] = 0.0              # zero query: the first k candidate docids, some of them in second-pass tiles
+    if awkward:
+        vectors[100000, 0] = np.inf   # non-finite rows: their tile takes the chunked walk; NaN distances sort last
+        vectors[100300, 3] = np.nan
+        queries[5] = 0.0              # zero query: the first k candidate docids, some of them in second-pass tiles
     if pass_percent is None:
         mask = None
     elif pass_percent == "top third":

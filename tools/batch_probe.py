@@ -10,7 +10,11 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import device_mask  # noqa: E402
+from bench import device_mask as _device_mask  # noqa: E402
+
+
+def device_mask(first, n, p, dev):
+    return _device_mask(torch, first, n, p, dev)
 
 
 def main():
