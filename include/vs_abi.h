@@ -233,6 +233,10 @@ typedef struct vs_mask vs_mask;
 int32_t vs_mask_create(vs_store* s, const uint64_t* mask_words, uint64_t n_mask_words, vs_mask** out);
 int32_t vs_mask_create_roaring(vs_store* s, const uint8_t* roaring_bytes, size_t len, vs_mask** out);
 int32_t vs_mask_destroy(vs_mask* m);
+/* 1 if `m` was created for `s` and still matches its size (vs_store_reserve
+ * outdates a mask), else 0. Never fails; reads nothing of the store the mask
+ * was created for, which may be gone. */
+int32_t vs_mask_fits(vs_store* s, const vs_mask* m);
 /* vs_search with the candidates of `mask` (NULL = every item). */
 int32_t vs_search_mask(vs_store* s, const float* query, uint32_t dim, uint32_t k, const vs_mask* mask,
                        uint32_t* out_ids, float* out_dist, uint32_t* out_n);

@@ -64,6 +64,7 @@ SIGNATURES = {
     "vs_mask_create": [_vp, _u64p, _u64, ctypes.POINTER(_vp)],
     "vs_mask_create_roaring": [_vp, _u8p, _sz, ctypes.POINTER(_vp)],
     "vs_mask_destroy": [_vp],
+    "vs_mask_fits": [_vp, _vp],
     "vs_search_mask": [_vp, _f32p, _u32, _u32, _vp, _u32p, _f32p, _u32p],
     "vs_search_workspace_bytes": [_vp, _u32, _u64p],
     "vs_search_device": [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp],
@@ -333,6 +334,10 @@ class Store:
 
     def destroy_mask(self, handle):
         self._ck(lib.vs_mask_destroy(handle))
+
+    def mask_fits(self, handle):
+        """Whether the mask was created for this store at its present size."""
+        return bool(lib.vs_mask_fits(self.handle, handle))
 
     def search_mask(self, query, k, mask_handle):
         query = np.ascontiguousarray(query, np.float32)

@@ -100,16 +100,35 @@ int main(int argc, char** argv) {
             return execute_vector_search(gctx, v, universe, 0, limit + offset, "default",
                                          DistributionShift::create(0.5f, 0.15f));
         };
-        double secs[4] = {0, 0, 0, 0};
+        double secs[5] = {0, 0, 0, 0, 0};
         uint64_t hits = 0;
         vs_mask* kept = nullptr;  // the same filter, uploaded once
         CHECK(vs_mask_create(store, universe.words().data(), universe.words().size(), &kept));
         // 0: vector search alone, 1: hybrid, 2: the bare vs_search call, 3: vs_search_mask with the kept filter
-        for (int mode = 0; mode < 4; ++mode) {
+        // (0 and 1 hand over the SAME universe object every time: a host that keeps the bitmap of a facet
+        // filter it has evaluated before), 4: hybrid with a universe that was never seen before (a filter
+        // evaluated for this request: its cardinality is counted and its words are uploaded inside the call)
+        for (int mode = 0; mode < 5; ++mode) {
+            std::vector<DocSet> fresh;
+            if (mode == 4)
+                for (int i = -5; i < n_queries; ++i) fresh.push_back(DocSet::from_words(universe.words()));
             for (int i = -5; i < n_queries; ++i) {  // 5 untimed warm-up calls
                 const auto t0 = std::chrono::steady_clock::now();
                 const std::vector<float>& q = queries[(size_t)(i + 5) % queries.size()];
-                if (mode == 0) {
+                if (mode == 4) {
+                    HybridInput in;
+                    in.query = std::string("query");
+                    in.has_semantic = true;
+                    in.vector = q;
+                    in.offset = offset;
+                    in.limit = limit;
+                    in.keyword_search = [&]() { return keyword; };
+                    in.vector_search = [&](const std::vector<float>& v) {
+                        return execute_vector_search(gctx, v, std::move(fresh[(size_t)(i + 5)]), 0, limit + offset,
+                                                     "default", DistributionShift::create(0.5f, 0.15f));
+                    };
+                    hits += execute_hybrid(in, 0.5f).first.documents_ids.size();
+                } else if (mode == 0) {
                     hits += vector_search(q).documents_ids.size();
                 } else if (mode == 2) {
                     uint32_t ids[16], n = 0;
@@ -138,10 +157,12 @@ int main(int argc, char** argv) {
         }
         std::printf("{\"workload\": \"hybrid, semanticRatio 0.5, %llu docs x %u f32, top-%llu, facet pass rate %d%%\", "
                     "\"vector_search_qps\": %.1f, \"vector_search_ms\": %.4f, \"hybrid_qps\": %.1f, \"hybrid_ms\": %.4f, "
-                    "\"bare_vs_search_ms\": %.4f, \"vs_search_mask_ms\": %.4f, "
+                    "\"bare_vs_search_ms\": %.4f, \"vs_search_mask_ms\": %.4f, \"hybrid_fresh_universe_ms\": %.4f, "
+                    "\"hybrid_over_vs_search_mask\": %.3f, \"hybrid_fresh_over_bare_vs_search\": %.3f, "
                     "\"queries\": %d, \"universe\": %zu, \"hits\": %llu}\n",
                     (unsigned long long)docs, dim, (unsigned long long)limit, pass, n_queries / secs[0],
-                    1e3 * secs[0] / n_queries, n_queries / secs[1], 1e3 * secs[1] / n_queries, 1e3 * secs[2] / n_queries, 1e3 * secs[3] / n_queries, n_queries, u.size(),
+                    1e3 * secs[0] / n_queries, n_queries / secs[1], 1e3 * secs[1] / n_queries, 1e3 * secs[2] / n_queries, 1e3 * secs[3] / n_queries, 1e3 * secs[4] / n_queries, secs[1] / secs[3],
+                    secs[4] / secs[2], n_queries, u.size(),
                     (unsigned long long)hits);
         std::fflush(stdout);
         CHECK(vs_mask_destroy(kept));

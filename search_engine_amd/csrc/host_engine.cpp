@@ -14,58 +14,129 @@ namespace search_engine {
 
 // ---- DocSet -------------------------------------------------------------------------
 
+namespace {
+inline uint64_t popcount64(uint64_t x) { return (uint64_t)__builtin_popcountll(x); }
+uint64_t count_bits(const std::vector<uint64_t>& w) {
+    uint64_t n = 0;
+    for (uint64_t x : w) n += popcount64(x);
+    return n;
+}
+std::vector<uint64_t> range_words(uint64_t n) {
+    std::vector<uint64_t> w((size_t)((n + 63) / 64), ~0ull);
+    if (n & 63) w.back() = (1ull << (n & 63)) - 1;
+    return w;
+}
+}  // namespace
+
 DocSet DocSet::from_ids(const std::vector<DocumentId>& ids) {
     DocSet s;
     if (ids.size() <= SMALL_MAX) {
         s.ids_ = ids;
         std::sort(s.ids_.begin(), s.ids_.end());
         s.ids_.erase(std::unique(s.ids_.begin(), s.ids_.end()), s.ids_.end());
-    } else {
-        s.small_ = false;
-        DocumentId top = 0;
-        for (DocumentId d : ids) top = std::max(top, d);
-        s.dense_ = std::make_shared<std::vector<uint64_t>>((size_t)(top >> 6) + 1, 0);
-        for (DocumentId d : ids) (*s.dense_)[d >> 6] |= 1ull << (d & 63);
+        return s;
     }
+    DocumentId top = 0;
+    for (DocumentId d : ids) top = std::max(top, d);
+    auto block = std::make_shared<Block>(std::vector<uint64_t>((size_t)(top >> 6) + 1, 0));
+    uint64_t n = 0;
+    for (DocumentId d : ids) {
+        uint64_t& w = block->w[d >> 6];
+        const uint64_t bit = 1ull << (d & 63);
+        n += !(w & bit);
+        w |= bit;
+    }
+    if (n == (uint64_t)top + 1) return from_range(n);  // every docid up to the largest: no holes
+    block->len = (int64_t)n;
+    s.kind_ = Bitmap;
+    s.dense_ = std::move(block);
     return s;
 }
 DocSet DocSet::from_words(std::vector<uint64_t> words) {
     DocSet s;
-    s.small_ = false;
-    s.dense_ = std::make_shared<std::vector<uint64_t>>(std::move(words));
+    s.kind_ = Bitmap;
+    s.dense_ = std::make_shared<Block>(std::move(words));
     return s;
 }
-static std::shared_ptr<std::vector<uint64_t>> words_of(const std::vector<DocumentId>& ids) {
-    auto w = std::make_shared<std::vector<uint64_t>>(ids.empty() ? 0 : (size_t)(ids.back() >> 6) + 1, 0);
-    for (DocumentId d : ids) (*w)[d >> 6] |= 1ull << (d & 63);
-    return w;
+DocSet DocSet::from_range(uint64_t n) {
+    DocSet s;
+    if (n) {
+        s.kind_ = Range;
+        s.range_n_ = n;
+    }
+    return s;
 }
-void DocSet::to_dense() {
-    dense_ = words_of(ids_);
-    small_ = false;
+const char* DocSet::representation() const {
+    return kind_ == Array ? "array" : kind_ == Range ? "range" : "bitmap";
+}
+void DocSet::to_bitmap() {
+    if (kind_ == Bitmap) return;
+    std::vector<uint64_t> w;
+    if (kind_ == Range) {
+        w = range_words(range_n_);
+    } else if (!ids_.empty()) {
+        w.assign((size_t)(ids_.back() >> 6) + 1, 0);
+        for (DocumentId d : ids_) w[d >> 6] |= 1ull << (d & 63);
+    }
+    const int64_t n = kind_ == Range ? (int64_t)range_n_ : (int64_t)ids_.size();
+    dense_ = std::make_shared<Block>(std::move(w));
+    dense_->len = n;
+    kind_ = Bitmap;
     ids_.clear();
+    range_n_ = 0;
     cache_.reset();
 }
 std::vector<uint64_t>& DocSet::own() {
-    if (!dense_) dense_ = std::make_shared<std::vector<uint64_t>>();
-    else if (dense_.use_count() > 1) dense_ = std::make_shared<std::vector<uint64_t>>(*dense_);
-    return *dense_;
-}
-const std::vector<uint64_t>& DocSet::words() const {
-    static const std::vector<uint64_t> none;
-    if (small_) {
-        if (!cache_) cache_ = words_of(ids_);
-        return *cache_;
+    if (!dense_) {
+        dense_ = std::make_shared<Block>();
+        dense_->len = 0;
+    } else if (dense_.use_count() > 1) {
+        auto mine = std::make_shared<Block>(dense_->w);
+        mine->len = dense_->len.load();
+        dense_ = std::move(mine);
+    } else {
+        std::lock_guard<std::mutex> g(dense_->mu);
+        dense_->attached.clear();  // whatever was derived from the words is stale from here on
     }
-    return dense_ ? *dense_ : none;
+    return dense_->w;
+}
+const DocSet::Block& DocSet::word_block() const {
+    static const Block none;
+    if (kind_ == Bitmap) return dense_ ? *dense_ : none;
+    if (!cache_) {
+        DocSet copy = *this;
+        copy.cache_.reset();
+        copy.to_bitmap();
+        cache_ = copy.dense_;
+    }
+    return *cache_;
+}
+const std::vector<uint64_t>& DocSet::words() const { return word_block().w; }
+std::shared_ptr<void> DocSet::attachment(const void* owner) const {
+    Block& b = const_cast<Block&>(word_block());
+    std::lock_guard<std::mutex> g(b.mu);
+    for (auto& kv : b.attached)
+        if (kv.first == owner) return kv.second;
+    return nullptr;
+}
+void DocSet::attach(const void* owner, std::shared_ptr<void> what) const {
+    Block& b = const_cast<Block&>(word_block());
+    std::lock_guard<std::mutex> g(b.mu);
+    for (auto& kv : b.attached)
+        if (kv.first == owner) {
+            kv.second = std::move(what);
+            return;
+        }
+    b.attached.emplace_back(owner, std::move(what));
 }
 bool DocSet::contains(DocumentId d) const {
-    if (small_) return std::binary_search(ids_.begin(), ids_.end(), d);
+    if (kind_ == Array) return std::binary_search(ids_.begin(), ids_.end(), d);
+    if (kind_ == Range) return (uint64_t)d < range_n_;
     const size_t wi = d >> 6;
-    return dense_ && wi < dense_->size() && (((*dense_)[wi] >> (d & 63)) & 1);
+    return dense_ && wi < dense_->w.size() && ((dense_->w[wi] >> (d & 63)) & 1);
 }
 bool DocSet::insert(DocumentId d) {
-    if (small_) {
+    if (kind_ == Array) {
         auto it = std::lower_bound(ids_.begin(), ids_.end(), d);
         if (it != ids_.end() && *it == d) return false;
         if (ids_.size() < SMALL_MAX) {
@@ -73,18 +144,26 @@ bool DocSet::insert(DocumentId d) {
             cache_.reset();
             return true;
         }
-        to_dense();
+        to_bitmap();
+    } else if (kind_ == Range) {
+        if ((uint64_t)d < range_n_) return false;
+        if ((uint64_t)d == range_n_) {
+            ++range_n_;
+            cache_.reset();
+            return true;
+        }
+        to_bitmap();
     }
+    if (contains(d)) return false;
     std::vector<uint64_t>& w = own();
     const size_t wi = d >> 6;
     if (wi >= w.size()) w.resize(wi + 1, 0);
-    const uint64_t bit = 1ull << (d & 63);
-    const bool fresh = !(w[wi] & bit);
-    w[wi] |= bit;
-    return fresh;
+    w[wi] |= 1ull << (d & 63);
+    if (dense_->len >= 0) ++dense_->len;
+    return true;
 }
 bool DocSet::remove(DocumentId d) {
-    if (small_) {
+    if (kind_ == Array) {
         auto it = std::lower_bound(ids_.begin(), ids_.end(), d);
         if (it == ids_.end() || *it != d) return false;
         ids_.erase(it);
@@ -92,43 +171,76 @@ bool DocSet::remove(DocumentId d) {
         return true;
     }
     if (!contains(d)) return false;
+    if (kind_ == Range) {
+        if ((uint64_t)d + 1 == range_n_) {
+            if (--range_n_ == 0) kind_ = Array;
+            cache_.reset();
+            return true;
+        }
+        to_bitmap();
+    }
     own()[d >> 6] &= ~(1ull << (d & 63));
+    if (dense_->len >= 0) --dense_->len;
     return true;
 }
 uint64_t DocSet::len() const {
-    if (small_) return ids_.size();
-    uint64_t n = 0;
-    if (dense_)
-        for (uint64_t w : *dense_) n += (uint64_t)__builtin_popcountll(w);
-    return n;
+    if (kind_ == Array) return ids_.size();
+    if (kind_ == Range) return range_n_;
+    if (!dense_) return 0;
+    int64_t n = dense_->len;
+    if (n < 0) dense_->len = n = (int64_t)count_bits(dense_->w);
+    return (uint64_t)n;
 }
 bool DocSet::is_empty() const {
-    if (small_) return ids_.empty();
-    if (dense_)
-        for (uint64_t w : *dense_)
-            if (w) return false;
+    if (kind_ == Array) return ids_.empty();
+    if (kind_ == Range) return range_n_ == 0;
+    if (!dense_) return true;
+    if (dense_->len >= 0) return dense_->len == 0;
+    for (uint64_t w : dense_->w)
+        if (w) return false;
     return true;
 }
 DocSet DocSet::intersect(const DocSet& o, uint64_t* len) const {
     DocSet r;
-    if (small_ || o.small_) {  // walk the small one, probe the other
-        const DocSet& a = small_ ? *this : o;
-        const DocSet& b = small_ ? o : *this;
+    if (kind_ == Array || o.kind_ == Array) {  // walk the array, probe the other
+        const DocSet& a = kind_ == Array ? *this : o;
+        const DocSet& b = kind_ == Array ? o : *this;
         for (DocumentId d : a.ids_)
             if (b.contains(d)) r.ids_.push_back(d);
         if (len) *len = r.ids_.size();
         return r;
     }
-    r.small_ = false;
+    if (kind_ == Range && o.kind_ == Range) {
+        r = from_range(std::min(range_n_, o.range_n_));
+        if (len) *len = r.range_n_;
+        return r;
+    }
+    if (kind_ == Range || o.kind_ == Range) {
+        const uint64_t n = kind_ == Range ? range_n_ : o.range_n_;
+        const DocSet& b = kind_ == Range ? o : *this;
+        const size_t have = b.dense_ ? b.dense_->w.size() : 0;
+        if (n >= (uint64_t)have * 64) {  // the range covers the bitmap: the result IS the bitmap
+            r = b;
+            if (len) *len = r.len();
+            return r;
+        }
+        std::vector<uint64_t> w(b.dense_->w.begin(), b.dense_->w.begin() + (size_t)((n + 63) / 64));
+        if (n & 63) w.back() &= (1ull << (n & 63)) - 1;
+        r = from_words(std::move(w));
+        if (len) *len = r.len();
+        return r;
+    }
+    r.kind_ = Bitmap;
     const std::vector<uint64_t>& x = words();
     const std::vector<uint64_t>& y = o.words();
-    r.dense_ = std::make_shared<std::vector<uint64_t>>(std::min(x.size(), y.size()));
+    r.dense_ = std::make_shared<Block>(std::vector<uint64_t>(std::min(x.size(), y.size())));
     uint64_t n = 0;
-    for (size_t i = 0; i < r.dense_->size(); ++i) {
+    for (size_t i = 0; i < r.dense_->w.size(); ++i) {
         const uint64_t w = x[i] & y[i];
-        (*r.dense_)[i] = w;
-        n += (uint64_t)__builtin_popcountll(w);
+        r.dense_->w[i] = w;
+        n += popcount64(w);
     }
+    r.dense_->len = (int64_t)n;
     if (len) *len = n;
     return r;
 }
@@ -139,36 +251,50 @@ DocSet DocSet::operator|(const DocSet& o) const {
     return r;
 }
 DocSet& DocSet::operator|=(const DocSet& o) {
-    if (o.small_) {
+    if (o.kind_ == Array) {
         for (DocumentId d : o.ids_) insert(d);
         return *this;
     }
-    if (small_) to_dense();
+    if (kind_ == Range && o.kind_ == Range) {
+        range_n_ = std::max(range_n_, o.range_n_);
+        cache_.reset();
+        return *this;
+    }
+    to_bitmap();
     std::vector<uint64_t>& w = own();
     const std::vector<uint64_t>& y = o.words();
     if (y.size() > w.size()) w.resize(y.size(), 0);
     for (size_t i = 0; i < y.size(); ++i) w[i] |= y[i];
+    dense_->len = -1;
     return *this;
 }
 DocSet& DocSet::operator-=(const DocSet& o) {
-    if (small_) {
+    if (kind_ == Array) {
         ids_.erase(std::remove_if(ids_.begin(), ids_.end(), [&](DocumentId d) { return o.contains(d); }), ids_.end());
         cache_.reset();
         return *this;
     }
-    if (o.small_) {
+    if (o.kind_ == Array) {
         for (DocumentId d : o.ids_) remove(d);
         return *this;
     }
+    if (o.is_empty()) return *this;
+    to_bitmap();
     std::vector<uint64_t>& w = own();
     const std::vector<uint64_t>& y = o.words();
     const size_t n = std::min(w.size(), y.size());
     for (size_t i = 0; i < n; ++i) w[i] &= ~y[i];
+    dense_->len = -1;
     return *this;
 }
 std::vector<DocumentId> DocSet::to_ids() const {
-    if (small_) return ids_;
+    if (kind_ == Array) return ids_;
     std::vector<DocumentId> ids;
+    if (kind_ == Range) {
+        ids.resize((size_t)range_n_);
+        for (uint64_t i = 0; i < range_n_; ++i) ids[(size_t)i] = (DocumentId)i;
+        return ids;
+    }
     const std::vector<uint64_t>& x = words();
     for (size_t i = 0; i < x.size(); ++i) {
         uint64_t w = x[i];
@@ -474,6 +600,20 @@ std::string last_error(vs_ctx* ctx) {
     return buf;
 }
 
+// What a GpuReader leaves with a candidate set's words: how often it has searched under them and,
+// from the second search on, their copy in device memory. A set that is searched once (a request's
+// universe that never comes back) is sent along with its search; one that comes back (a refill of
+// the same request, the next request under the same facet filter) is uploaded once more, into a
+// vs_mask, and every later search names that mask instead of sending N / 8 bytes again.
+struct DeviceMaskSlot {
+    std::mutex mu;
+    uint32_t searches = 0;
+    vs_mask* mask = nullptr;
+    ~DeviceMaskSlot() {
+        if (mask) vs_mask_destroy(mask);
+    }
+};
+
 class GpuReader : public Reader {
    public:
     GpuReader(vs_ctx* ctx, vs_store* store) : ctx_(ctx), store_(store) {}
@@ -484,20 +624,18 @@ class GpuReader : public Reader {
         std::vector<uint32_t> ids(count ? count : 1);
         std::vector<float> dist(count ? count : 1);
         uint32_t n = 0;
-        static const uint64_t none = 0;
-        const std::vector<uint64_t>& w = candidates.words();
-        // an empty candidate set is an empty mask, not "no filter"
-        const int32_t rc = vs_search(store_, target.data(), (uint32_t)target.size(), (uint32_t)count,
-                                     w.empty() ? &none : w.data(), w.size(), ids.data(), dist.data(), &n);
-        if (rc == VS_E_DIM_MISMATCH) {
-            uint32_t e = 0, r = 0;
-            vs_last_dim_mismatch(ctx_, &e, &r);
-            throw Error(Error::InvalidVectorDimensions,
-                        "Invalid vector dimensions: expected: `" + std::to_string(e) + "`, found: `" +
-                            std::to_string(r) + "`.",
-                        e, r);
+        int32_t rc;
+        if (const vs_mask* mask = kept_mask(candidates)) {
+            rc = vs_search_mask(store_, target.data(), (uint32_t)target.size(), (uint32_t)count, mask, ids.data(),
+                                dist.data(), &n);
+        } else {
+            static const uint64_t none = 0;
+            const std::vector<uint64_t>& w = candidates.words();
+            // an empty candidate set is an empty mask, not "no filter"
+            rc = vs_search(store_, target.data(), (uint32_t)target.size(), (uint32_t)count,
+                           w.empty() ? &none : w.data(), w.size(), ids.data(), dist.data(), &n);
         }
-        if (rc != VS_OK) throw Error(Error::ArroyError, last_error(ctx_));
+        check(rc);
         std::vector<std::pair<DocumentId, float>> out(n);
         for (uint32_t i = 0; i < n; ++i) out[i] = {ids[i], dist[i]};
         return out;
@@ -518,10 +656,25 @@ class GpuReader : public Reader {
         }
         std::vector<uint32_t> ids(n_q * kk), n(n_q, 0);
         std::vector<float> dist(n_q * kk);
-        static const uint64_t none = 0;
-        const std::vector<uint64_t>& w = candidates.words();
-        const int32_t rc = vs_search_batch(store_, flat.data(), (uint32_t)n_q, (uint32_t)dim, (uint32_t)count,
-                                           w.empty() ? &none : w.data(), w.size(), ids.data(), dist.data(), n.data());
+        int32_t rc;
+        if (const vs_mask* mask = kept_mask(candidates)) {
+            const std::vector<const vs_mask*> masks(n_q, mask);  // one filter: the queries share passes
+            rc = vs_search_batch_masks(store_, flat.data(), (uint32_t)n_q, (uint32_t)dim, (uint32_t)count, nullptr,
+                                       nullptr, masks.data(), ids.data(), dist.data(), n.data());
+        } else {
+            static const uint64_t none = 0;
+            const std::vector<uint64_t>& w = candidates.words();
+            rc = vs_search_batch(store_, flat.data(), (uint32_t)n_q, (uint32_t)dim, (uint32_t)count,
+                                 w.empty() ? &none : w.data(), w.size(), ids.data(), dist.data(), n.data());
+        }
+        check(rc);
+        for (size_t i = 0; i < n_q; ++i)
+            for (uint32_t j = 0; j < n[i]; ++j) out[i].emplace_back(ids[i * count + j], dist[i * count + j]);
+        return out;
+    }
+
+   private:
+    void check(int32_t rc) {
         if (rc == VS_E_DIM_MISMATCH) {
             uint32_t e = 0, r = 0;
             vs_last_dim_mismatch(ctx_, &e, &r);
@@ -531,12 +684,31 @@ class GpuReader : public Reader {
                         e, r);
         }
         if (rc != VS_OK) throw Error(Error::ArroyError, last_error(ctx_));
-        for (size_t i = 0; i < n_q; ++i)
-            for (uint32_t j = 0; j < n[i]; ++j) out[i].emplace_back(ids[i * count + j], dist[i * count + j]);
-        return out;
     }
-
-   private:
+    // The device copy of `candidates` for this store, or nullptr: send the words with the search.
+    // Stores of one context never share an address while both live, so the store pointer names
+    // the slot; a mask that no longer fits its store (the store was given more room, or its
+    // address has been reused) is dropped and made again.
+    const vs_mask* kept_mask(const DocSet& candidates) {
+        std::shared_ptr<void> held = candidates.attachment(store_);
+        if (!held) {
+            held = std::make_shared<DeviceMaskSlot>();
+            candidates.attach(store_, held);
+        }
+        DeviceMaskSlot& slot = *static_cast<DeviceMaskSlot*>(held.get());
+        std::lock_guard<std::mutex> g(slot.mu);
+        if (slot.mask && !vs_mask_fits(store_, slot.mask)) {
+            vs_mask_destroy(slot.mask);
+            slot.mask = nullptr;
+        }
+        if (!slot.mask && slot.searches++ >= 1) {
+            static const uint64_t none = 0;
+            const std::vector<uint64_t>& w = candidates.words();
+            if (vs_mask_create(store_, w.empty() ? &none : w.data(), w.size(), &slot.mask) != VS_OK)
+                slot.mask = nullptr;  // no room on the device: the plain search reports what is wrong
+        }
+        return slot.mask;
+    }
     vs_ctx* ctx_;
     vs_store* store_;
 };
@@ -602,16 +774,20 @@ void VectorSort::set_cache(std::vector<std::vector<std::pair<DocumentId, float>>
     cursor_ = 0;
 }
 
-void VectorSort::fill_buffer(const DocSet& vector_candidates) {
+void VectorSort::fill_buffer() {
     if (preloaded_) {  // the first fill was computed for this rule together with other queries'
         auto r = std::move(*preloaded_);
         preloaded_.reset();
         set_cache(std::move(r));
         return;
     }
+    if (!emitted_.is_empty()) {  // a refill: the documents handed out so far leave the candidates for good
+        live_ -= emitted_;
+        emitted_ = DocSet();
+    }
     std::vector<std::vector<std::pair<DocumentId, float>>> per_store;
     for (auto& reader : open_readers(ctx_, embedder_index_))
-        per_store.push_back(reader->nns_by_vector(target_, limit_, vector_candidates));
+        per_store.push_back(reader->nns_by_vector(target_, limit_, live_));
     set_cache(std::move(per_store));
 }
 
@@ -622,7 +798,8 @@ void VectorSort::preload(std::vector<std::vector<std::pair<DocumentId, float>>> 
 void VectorSort::start_iteration(DocSet candidates) {
     candidates_len_ = candidates.len();
     live_ = vector_candidates_.intersect(candidates, &live_len_);
-    fill_buffer(live_);
+    emitted_ = DocSet();
+    fill_buffer();
 }
 
 std::optional<RankingRuleOutput> VectorSort::next_bucket() {
@@ -636,17 +813,17 @@ std::optional<RankingRuleOutput> VectorSort::next_bucket() {
         }
         while (cursor_ < cached_sorted_docids_.size()) {
             const auto [docid, distance] = cached_sorted_docids_[cursor_++];
-            if (live_.contains(docid)) {
+            if (live_.contains(docid) && !emitted_.contains(docid)) {
                 float score = 1.0f - distance;
                 if (distribution_shift_) score = distribution_shift_->shift(score);
-                live_.remove(docid);
+                emitted_.insert(docid);
                 --candidates_len_;
                 --live_len_;
                 return RankingRuleOutput{ScoreDetails::vector(score), DocSet::from_ids({docid})};
             }
         }
         // the cache is exhausted: refill it and run again
-        fill_buffer(live_);
+        fill_buffer();
         if (cached_sorted_docids_.empty()) {
             // no document with a vector is left in the universe
             candidates_len_ = 0;

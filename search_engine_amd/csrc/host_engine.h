@@ -20,9 +20,11 @@
 #pragma once
 #include <stdint.h>
 
+#include <atomic>
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -54,40 +56,61 @@ struct Error : std::runtime_error {
 
 // ---- docid sets ----------------------------------------------------------------
 
-// The handful of RoaringBitmap operations the path uses. Like a roaring bitmap the set has
-// two representations: a sorted array while it is small (a one-document bucket, the documents
-// already returned) and a dense bitmap otherwise -- bit (d & 63) of word d >> 6, the layout
-// vs_search takes as its candidate mask. Operations cost the size of the smaller operand
-// wherever a roaring bitmap's would; copies of a dense set share its words until one of them
-// is modified.
+// The handful of RoaringBitmap operations the path uses. Like a roaring bitmap the set picks
+// its representation: a sorted array while it is small (a one-document bucket, the documents
+// already returned), a range [0, n) when it holds every docid below n (the documents of an index
+// without holes: roaring's run container), and a dense bitmap otherwise -- bit (d & 63) of word
+// d >> 6, the layout vs_search takes as its candidate mask. Operations cost the size of the
+// smaller operand wherever a roaring bitmap's would; a range intersected with a bitmap IS that
+// bitmap. Copies of a dense set share its words (and the cardinality once it has been counted)
+// until one of them is modified. One DocSet object is for one thread at a time; copies of it may
+// be used from different threads.
 class DocSet {
    public:
     DocSet() = default;
     static DocSet from_ids(const std::vector<DocumentId>& ids);
     static DocSet from_words(std::vector<uint64_t> words);
+    static DocSet from_range(uint64_t n);  // the docids [0, n)
     bool contains(DocumentId d) const;
     bool insert(DocumentId d);  // true if newly inserted
     bool remove(DocumentId d);
     uint64_t len() const;
     bool is_empty() const;
     DocSet operator&(const DocSet& o) const;
-    // *this & o, and its cardinality, in one pass
+    // *this & o, and its cardinality
     DocSet intersect(const DocSet& o, uint64_t* len) const;
     DocSet operator|(const DocSet& o) const;
     DocSet& operator|=(const DocSet& o);
     DocSet& operator-=(const DocSet& o);
     std::vector<DocumentId> to_ids() const;  // ascending
-    // dense words (trailing zero words may be missing); materialised on demand for a small set
+    // dense words (trailing zero words may be missing); materialised on demand for an array or a range
     const std::vector<uint64_t>& words() const;
+    // What a data-access layer derived from words() and wants to find again for as long as these
+    // words live unchanged (the device copy of a candidate mask), one slot per owner. Copies that
+    // share the words share the slots; a modification drops them.
+    std::shared_ptr<void> attachment(const void* owner) const;
+    void attach(const void* owner, std::shared_ptr<void> what) const;
+    const char* representation() const;  // "array", "range" or "bitmap"
 
    private:
+    struct Block {
+        std::vector<uint64_t> w;
+        std::atomic<int64_t> len{-1};  // bits set, -1 = not counted yet
+        std::mutex mu;                 // guards `attached`
+        std::vector<std::pair<const void*, std::shared_ptr<void>>> attached;
+        Block() = default;
+        explicit Block(std::vector<uint64_t> words) : w(std::move(words)) {}
+    };
+    enum Kind { Array, Range, Bitmap };
     static constexpr size_t SMALL_MAX = 4096;  // roaring's array-container limit
-    void to_dense();                           // small_ -> dense
-    std::vector<uint64_t>& own();              // the dense words, unshared
-    bool small_ = true;
-    std::vector<DocumentId> ids_;                           // small_: ascending, unique
-    std::shared_ptr<std::vector<uint64_t>> dense_;          // !small_: the bitmap, shared between copies
-    mutable std::shared_ptr<std::vector<uint64_t>> cache_;  // small_: what words() last built
+    void to_bitmap();                          // array or range -> bitmap
+    std::vector<uint64_t>& own();              // the bitmap's words, unshared, attachments dropped
+    const Block& word_block() const;           // the block words() hands out
+    Kind kind_ = Array;
+    std::vector<DocumentId> ids_;           // Array: ascending, unique
+    uint64_t range_n_ = 0;                  // Range
+    std::shared_ptr<Block> dense_;          // Bitmap: shared between copies
+    mutable std::shared_ptr<Block> cache_;  // Array, Range: what words() last built
 };
 
 // ---- DistributionShift -----------------------------------------------------------
@@ -229,7 +252,7 @@ class VectorSort : public RankingRule {
     static std::vector<std::unique_ptr<Reader>> open_readers(Context& ctx, uint8_t embedder_index);
 
    private:
-    void fill_buffer(const DocSet& vector_candidates);
+    void fill_buffer();
     void set_cache(std::vector<std::vector<std::pair<DocumentId, float>>> per_store_results);
     std::optional<std::vector<std::vector<std::pair<DocumentId, float>>>> preloaded_;
     Context& ctx_;
@@ -237,8 +260,10 @@ class VectorSort : public RankingRule {
     DocSet vector_candidates_;
     // The reference keeps `candidates`, removes every emitted document from it and recomputes
     // vector_candidates & candidates in every next_bucket (vector_sort.rs:100,118). Only that
-    // intersection and the two cardinalities are ever looked at, so they are what is kept.
-    DocSet live_;
+    // intersection and the two cardinalities are ever looked at, so they are what is kept: live_ as
+    // of the last (re)fill -- untouched in between, so that it can share its words with the
+    // caller's universe and keep their device copy -- and the documents emitted since.
+    DocSet live_, emitted_;
     uint64_t candidates_len_ = 0, live_len_ = 0;
     std::vector<std::pair<DocumentId, float>> cached_sorted_docids_;
     size_t cursor_ = 0;

@@ -357,6 +357,52 @@ PYBIND11_MODULE(_host, m) {
         }));
 
     m.def("assign_embedder_category_ids", &assign_embedder_category_ids);
+    // One round of DocSet algebra for the tests: `a` and `b` are built as to_docset builds them (or
+    // as the range [0, n) from an int), then `script` is played on a copy of `a`: ("insert", d),
+    // ("remove", d), ("or", ), ("sub", ). Everything a DocSet can be asked is returned.
+    m.def("docset_probe", [](const py::object& a_in, const py::object& b_in, const py::list& script,
+                             const std::vector<DocumentId>& probes) {
+        auto build = [](const py::object& o) {
+            return py::isinstance<py::int_>(o) ? DocSet::from_range(o.cast<uint64_t>()) : to_docset(o);
+        };
+        const DocSet a = build(a_in), b = build(b_in);
+        py::dict out;
+        out["a_repr"] = a.representation();
+        out["b_repr"] = b.representation();
+        uint64_t n_and = 0;
+        const DocSet both = a.intersect(b, &n_and);
+        out["and"] = from_docset(both);
+        out["and_len"] = n_and;
+        out["and_repr"] = both.representation();
+        out["and_len_again"] = both.len();
+        out["or"] = from_docset(a | b);
+        DocSet diff = a;
+        diff -= b;
+        out["sub"] = from_docset(diff);
+        out["sub_len"] = diff.len();
+        out["a_after_ops"] = from_docset(a);  // copies were modified, not `a`
+        DocSet c = a;
+        py::list effects;
+        for (py::handle step : script) {
+            const py::tuple t = py::reinterpret_borrow<py::tuple>(step);
+            const std::string op = t[0].cast<std::string>();
+            if (op == "insert") effects.append(c.insert(t[1].cast<DocumentId>()));
+            else if (op == "remove") effects.append(c.remove(t[1].cast<DocumentId>()));
+            else if (op == "or") c |= b;
+            else if (op == "sub") c -= b;
+            effects.append(c.len());
+        }
+        out["effects"] = effects;
+        out["c"] = from_docset(c);
+        out["c_repr"] = c.representation();
+        out["c_empty"] = c.is_empty();
+        py::list hit;
+        for (DocumentId d : probes) hit.append(py::make_tuple(a.contains(d), c.contains(d)));
+        out["contains"] = hit;
+        const std::vector<uint64_t>& w = c.words();
+        out["c_words"] = py::array_t<uint64_t>((py::ssize_t)w.size(), w.data());
+        return out;
+    });
     py::class_<GpuWriters>(m, "GpuWriters")
         .def(py::init([](uintptr_t ctx_handle, uint8_t embedder_index, uint32_t dimension, uint64_t capacity) {
             return new GpuWriters(reinterpret_cast<vs_ctx*>(ctx_handle), embedder_index, dimension, capacity);
@@ -416,6 +462,22 @@ PYBIND11_MODULE(_host, m) {
           py::arg("ctx"), py::arg("vector"), py::arg("universe"), py::arg("skip"), py::arg("limit"),
           py::arg("embedder_name"), py::arg("distribution") = py::none(),
           py::arg("extra_rules") = py::none());
+
+    // execute_vector_search once per vector with ONE universe object, as a host does that keeps
+    // the bitmap of a facet filter across requests (what a reader left with the set stays with it)
+    m.def("execute_vector_search_same_universe",
+          [](py::object ctx, std::vector<std::vector<float>> vectors, py::object universe, uint64_t skip,
+             uint64_t limit, const std::string& embedder_name, py::object distribution) {
+              std::shared_ptr<Context> c = context_from_py(ctx);
+              const DocSet u = to_docset(universe);
+              py::list out;
+              for (const auto& v : vectors)
+                  out.append(result_to_py(execute_vector_search(*c, v, u, skip, limit, embedder_name,
+                                                                distribution_from_py(distribution))));
+              return out;
+          },
+          py::arg("ctx"), py::arg("vectors"), py::arg("universe"), py::arg("skip"), py::arg("limit"),
+          py::arg("embedder_name"), py::arg("distribution") = py::none());
 
     m.def("execute_vector_search_batch",
           [](py::object ctx, std::vector<std::vector<float>> vectors, py::object universe, uint64_t skip,

@@ -758,6 +758,9 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
         if (lane == 0) qcount[pp] = 0;
     };
 
+#ifdef VS_STAMP
+    const uint64_t stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (uint32_t j = 0; j < n_mine; ++j) {
         const uint32_t par = j & 1;
         // tile ids two ahead and the next tile's words are requested now and used a tile later
@@ -778,7 +781,9 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             // ... everyone's are; the previous step's readers are done with the other image
+#ifndef VS_ABL_NOBARRIER
             __builtin_amdgcn_s_barrier();
+#endif
             if (ks == 0) {
                 if (tid < (uint32_t)BM) {
                     // rows that are not candidates get a NaN norm: their t is NaN, which the running
@@ -795,23 +800,46 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
             image ^= 1u;
             const bool last = ks + 1 == KS;
             const uint32_t nt = last ? t1 : t0, nks = last ? 0 : ks + 1;  // (past the last tile: zeros)
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
+            // The fragments of sub-step kk + 1 are requested before the matrix instructions of kk:
+            // the compiler may not move an LDS read above an LDS-DMA (which writes LDS), and left to
+            // itself the scheduler sinks each read to its first use.
+            bf16x8 fa[2][2], fb[2][4];
+            auto read_frags = [&](int kk, bf16x8 (&xa)[2], bf16x8 (&xb)[4]) {
                 uint32_t fo_a = frag_a ^ ((uint32_t)kk << 5), fo_b = frag_b ^ ((uint32_t)kk << 5);
                 asm volatile("" : "+v"(fo_a), "+v"(fo_b));  // recompute per step, do not keep 8 addresses live
-                bf16x8 fa[2], fb[4];
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
-                    fa[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + m * 32 * 128 + fo_a));
+#ifdef VS_ABL_NOLDSREAD
+                    xa[m] = __builtin_bit_cast(bf16x8, u32x4{fo_a, 1u, 2u, 3u});
+#else
+                    xa[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + m * 32 * 128 + fo_a));
+#endif
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
-                    fb[n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + n * 32 * 128 + fo_b));
+#ifdef VS_ABL_NOLDSREAD
+                    xb[n] = __builtin_bit_cast(bf16x8, u32x4{fo_b, 1u, 2u, 3u});
+#else
+                    xb[n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + n * 32 * 128 + fo_b));
+#endif
+            };
+            read_frags(0, fa[0], fb[0]);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int cur = kk & 1;
+                if (kk < 3) read_frags(kk + 1, fa[cur ^ 1], fb[cur ^ 1]);
+                __builtin_amdgcn_sched_barrier(0);  // (the scheduler would sink the reads to their first use)
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
+#ifndef VS_ABL_NOLOAD
                     load_piece(nt, nks, image, kk * 2 + m);
+#endif
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
+#ifdef VS_ABL_NOMFMA
+                        asm volatile("" ::"v"(fa[cur][m]), "v"(fb[cur][n]));
+#else
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][m], fb[cur][n], acc[m][n], 0, 0, 0);
+#endif
                 }
             }
         }
@@ -869,6 +897,13 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
 #pragma unroll
         for (int i = 0; i < 4; ++i) w0[i] = w1[i];
     }
+#ifdef VS_STAMP
+    if (b == 7 && tid == 0) {
+        const uint64_t c = __builtin_amdgcn_s_memtime() - stamp_c0, r = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+        printf("stream: %u tiles, %llu cycles per tile, %.0f MHz\n", n_mine, (unsigned long long)(c / n_mine),
+               (double)c / (double)r * 100.0);
+    }
+#endif
     // the last tile's survivors, once every wave has tested its scores
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();

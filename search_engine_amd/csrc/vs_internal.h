@@ -94,6 +94,7 @@ struct vs_mask {
     vs_store* store;
     uint64_t* d_words;  // store->n_slots / 64 words, aligned with the store
     uint64_t n_slots;   // of the store when the mask was made (vs_store_reserve outdates it)
+    uint64_t store_serial;  // of that store: a later store at the same address is another store
 };
 
 // One arroy index as a row slab.
@@ -113,6 +114,7 @@ struct vs_mask {
 //     items never makes a search wait.
 struct vs_store {
     vs_ctx* ctx = nullptr;
+    uint64_t serial = 0;  // unique in the process, never reused
     uint16_t index = 0;
     uint32_t dim = 0;
     int32_t dtype = VS_F32, metric = VS_ANGULAR;

@@ -527,13 +527,14 @@ __global__ __launch_bounds__(WAVES * 64) void scan_multi_kernel(MultiArgs m) {
 //
 // v_mfma_f32_32x32x2_f32 multiplies exact f32 operands and accumulates like a chain of fmaf,
 // at 1/16 of the bf16 rate: 2 * 32 * dim flop per row are about what a CU can do in the row's
-// HBM time, so THIRTY-TWO queries ride on one pass over an f32 slab (measured on 10 M x 768:
-// 6.8 ms per pass against 4.4 ms for a single-query pass).
+// HBM time, so THIRTY-TWO queries ride on one pass over an f32 slab (measured on 10 M x 768,
+// k = 10: 5.5 to 5.7 ms for the main pass with two waves per SIMD, 6.55 ms with one, against
+// 4.4 ms for a single-query pass; 24.6 k of a tile's cycles are matrix instructions).
 // One wave = one 32-row x 32-query tile:
 //   * the 32 queries sit in LDS for the whole kernel (row-major, 4 floats of padding);
 //   * rows come from the candidate queue, so a filter skips rows exactly as in the
 //     single-query scan. A chunk = 32 floats of each of the 32 rows: four loads in which
-//     eight lanes cover one row's 128-byte line, three chunks requested ahead;
+//     eight lanes cover one row's 128-byte line, four or eight chunks requested ahead;
 //   * a chunk goes through a per-wave LDS staging tile (stride 36 floats) to turn "lane =
 //     piece of a row" into the operand layout "lane = row (mod 32), k = lane / 32"; lanes of
 //     the upper half read the floats 4 further, which merely permutes the order in which a
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(WAVES * 64) void scan_multi_kernel(MultiArgs m) {
 //     distance, compares with that query's k-th best (LDS, per wave) and inserts survivors
 //     into the query's sorted list in LDS itself -- the two halves of the wave take turns,
 //     they share queries.
-// Sums are k-ordered fmaf chains, not the lane tree of the scans above: distances agree with
+// Sums are two interleaved k-ordered fmaf chains, not the lane tree of the scans above: distances agree with
 // vs_search within rounding, not bit for bit. Angular and dot product only (a squared
 // distance assembled from norms and a product would cancel for near neighbours).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -550,7 +551,14 @@ constexpr int MQ = 32;                   // queries per pass
 constexpr uint32_t MQ_MAX_K = 32;        // per-wave lists of every query live in LDS
 constexpr uint32_t MQ_MAX_VECS = 192;    // 768 f32 per row: the query block must fit LDS
 constexpr int MQ_STAGE_STRIDE = 36;      // floats per staged row (32 + 4 against bank conflicts)
-constexpr int MQ_DEPTH = 8;              // chunks requested ahead (even: the fragment sets alternate): 32 KiB per wave
+constexpr int MQ_QCAP = 32 + 64;         // candidate queue entries per wave: one tile + one mask word
+// Waves per workgroup. A wave's matrix instructions and its other instructions do not overlap (the
+// co-execution counter of a one-wave-per-SIMD run reads zero), so the staging, address and queue
+// work of a tile hides only behind ANOTHER wave's matrix instructions: eight waves (two per SIMD)
+// whenever their lists fit beside the query block (k <= 10 at 768 dimensions), else four.
+// Chunks requested ahead per wave (even: the fragment sets alternate): 8 with four waves, 4 with
+// eight, 128 KiB per CU either way.
+constexpr size_t MQ_LDS_LIMIT = 160 * 1024;
 
 struct Mq32Args {
     ScanArgs s;               // query = first query; partial = first query's lists
@@ -560,7 +568,7 @@ struct Mq32Args {
     const uint64_t* bound;    // nullable: [n_q][k] ascending keys of an earlier pass over the SAMPLE words
     uint32_t words;           // 0 every word, 1 the sample words only, 2 all but the sample words
 };
-constexpr uint32_t MQ_SAMPLE_PERIOD = 64;  // a wave's t-th word is a sample word iff (t + wave) % 64 == 0
+constexpr uint32_t MQ_SAMPLE_PERIOD = 128;  // a wave's t-th word is a sample word iff (t + wave) % 128 == 0
 struct Mq32Words {
     uint32_t mode, w;
     __device__ __forceinline__ bool keep(uint64_t t) const {
@@ -570,18 +578,24 @@ struct Mq32Words {
 
 __host__ __device__ inline uint32_t mq32_chunks(uint32_t row_vecs) { return (row_vecs + 7) / 8; }
 __host__ __device__ inline uint32_t mq32_qstride(uint32_t row_vecs) { return mq32_chunks(row_vecs) * 32 + 4; }
-static size_t mq32_lds_bytes(uint32_t row_vecs, uint32_t k) {
+static size_t mq32_lds_bytes(uint32_t row_vecs, uint32_t k, uint32_t waves) {
     return (size_t)MQ * mq32_qstride(row_vecs) * 4          // queries
-           + (size_t)WAVES * 32 * MQ_STAGE_STRIDE * 4       // staging tiles
-           + (size_t)WAVES * MQ * k * 8                     // lists
-           + (size_t)WAVES * MQ * 8                         // k-th best per query
-           + (size_t)WAVES * 32 * 8                         // slot and norm of the tile's rows
-           + (size_t)WAVES * QCAP * 4                       // candidate queues
+           + (size_t)waves * 32 * MQ_STAGE_STRIDE * 4       // staging tiles
+           + (size_t)waves * MQ * k * 8                     // lists
+           + (size_t)waves * MQ * 8                         // k-th best per query
+           + (size_t)waves * 32 * 8                         // slot and norm of the tile's rows
+           + (size_t)waves * MQ_QCAP * 4                    // candidate queues
            + (size_t)MQ * 4;                                // query norms
 }
+static uint32_t mq32_waves(uint32_t row_vecs, uint32_t k) {
+    return mq32_lds_bytes(row_vecs, k, 8) <= MQ_LDS_LIMIT ? 8 : 4;
+}
 
-template <int METRIC>
-__global__ __launch_bounds__(WAVES * 64) void scan_mq32_kernel(Mq32Args m) {
+// WORDS (= Mq32Args::words) is a template argument so that the sample pass and the main pass carry
+// different kernel names in a profile; the kernel reads the run-time copy.
+template <int METRIC, int WORDS, int NW>
+__global__ __launch_bounds__(NW * 64) void scan_mq32_kernel(Mq32Args m) {
+    constexpr int WAVES = NW, QCAP = MQ_QCAP, MQ_DEPTH = NW == 8 ? 4 : 8;
     static_assert(METRIC == VS_ANGULAR || METRIC == VS_DOT, "angular or dot product");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ScanArgs& a = m.s;
@@ -669,9 +683,11 @@ __global__ __launch_bounds__(WAVES * 64) void scan_mq32_kernel(Mq32Args m) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) dst[i] = load_vec<true>(base[i] + (int32_t)v);
         };
-        f32x16 acc;
+        // two accumulators take alternate k-steps: a link of either chain waits for the link two
+        // back, which has left the pipeline by then, instead of for the one just issued
+        f32x16 acc, acc_odd;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+        for (int e = 0; e < 16; ++e) acc[e] = acc_odd[e] = 0.0f;
         u32x4 buf[MQ_DEPTH][4];
 #pragma unroll
         for (int d = 0; d < MQ_DEPTH; ++d) request((uint32_t)d, buf[d]);
@@ -725,7 +741,7 @@ __global__ __launch_bounds__(WAVES * 64) void scan_mq32_kernel(Mq32Args m) {
             const int nb = (d + 1) % MQ_DEPTH, ns = (d + 1) & 1, cs = d & 1;
             auto mfma2 = [&](const int mm, const int t0) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cs][mm][t0], fb[cs][mm][t0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cs][mm][t0 + 1], fb[cs][mm][t0 + 1], acc, 0, 0, 0);
+                acc_odd = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cs][mm][t0 + 1], fb[cs][mm][t0 + 1], acc_odd, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             };
             wave_lds_fence();
@@ -764,6 +780,8 @@ __global__ __launch_bounds__(WAVES * 64) void scan_mq32_kernel(Mq32Args m) {
         for (int d = 0; d < MQ_DEPTH; ++d)  // fewer than MQ_DEPTH chunks are left
             if (c0 + (uint32_t)d < n_chunks) step(c0 + (uint32_t)d, d);
         wave_lds_fence();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] += acc_odd[e];
 #ifdef VS_MQ_STAMP
         const uint64_t s1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1612,7 +1630,7 @@ uint32_t scan_mq32_blocks(const SlabView& s) {
     const uint64_t want = (s.n_slots + 1023) / 1024;
     return (uint32_t)(want < 1 ? 1 : want > NUM_CUS ? NUM_CUS : want);  // the query block fills a CU's LDS
 }
-// Stores large enough that a bound from 1/64 of the words pays for a pass of its own: with it the
+// Stores large enough that a bound from 1/128 of the words pays for a pass of its own: with it the
 // main pass inserts next to nothing (without, every tile's epilogue runs the divergent insertion).
 static bool mq32_two_passes(const SlabView& s) { return s.n_slots >= (1u << 20); }
 uint64_t scan_mq32_partial_bytes(const SlabView& s, uint32_t k) {
@@ -1644,11 +1662,25 @@ hipError_t launch_scan_mq32(const SlabView& s, const float* d_queries, uint32_t 
     m.s.metric = s.metric;
     m.query_stride = query_stride;
     m.n_q = n_q;
-    const size_t lds = mq32_lds_bytes(s.row_vecs, k);
-    void (*kernel)(Mq32Args) = s.metric == VS_ANGULAR ? scan_mq32_kernel<VS_ANGULAR> : scan_mq32_kernel<VS_DOT>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+    const uint32_t nw = mq32_waves(s.row_vecs, k);
+    const size_t lds = mq32_lds_bytes(s.row_vecs, k, nw);
+    const bool ang = s.metric == VS_ANGULAR;
+    void (*sample_kernel)(Mq32Args);
+    void (*kernel)(Mq32Args);
+    if (nw == 8) {
+        sample_kernel = ang ? scan_mq32_kernel<VS_ANGULAR, 1, 8> : scan_mq32_kernel<VS_DOT, 1, 8>;
+        kernel = two ? (ang ? scan_mq32_kernel<VS_ANGULAR, 2, 8> : scan_mq32_kernel<VS_DOT, 2, 8>)
+                     : (ang ? scan_mq32_kernel<VS_ANGULAR, 0, 8> : scan_mq32_kernel<VS_DOT, 0, 8>);
+    } else {
+        sample_kernel = ang ? scan_mq32_kernel<VS_ANGULAR, 1, 4> : scan_mq32_kernel<VS_DOT, 1, 4>;
+        kernel = two ? (ang ? scan_mq32_kernel<VS_ANGULAR, 2, 4> : scan_mq32_kernel<VS_DOT, 2, 4>)
+                     : (ang ? scan_mq32_kernel<VS_ANGULAR, 0, 4> : scan_mq32_kernel<VS_DOT, 0, 4>);
+    }
+    hipError_t e = hipSuccess;
+    for (auto* f : {sample_kernel, kernel}) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     // workspace: main lists [MQ][blocks + 1][k] | sample lists [MQ][blocks][k] | sample top-k [MQ][k]
     uint64_t* main_lists = partial;
     uint64_t* sample_lists = partial + (uint64_t)MQ * (blocks + 1) * k;
@@ -1658,7 +1690,7 @@ hipError_t launch_scan_mq32(const SlabView& s, const float* d_queries, uint32_t 
         m.partial_stride = (uint64_t)blocks * k;
         m.bound = nullptr;
         m.words = 1;
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(WAVES * 64), lds, stream, m);
+        hipLaunchKernelGGL(sample_kernel, dim3(blocks), dim3(nw * 64), lds, stream, m);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         e = launch_merge_batch(sample_lists, blocks, k, 1, n_q, (uint64_t)blocks * k, k, s.metric, sample_top,
                                nullptr, nullptr, nullptr, stream);
@@ -1668,7 +1700,7 @@ hipError_t launch_scan_mq32(const SlabView& s, const float* d_queries, uint32_t 
     m.partial_stride = (uint64_t)(blocks + 1) * k;
     m.bound = two ? sample_top : nullptr;
     m.words = two ? 2 : 0;
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(WAVES * 64), lds, stream, m);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(nw * 64), lds, stream, m);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     return launch_merge_batch(main_lists, blocks + (two ? 1 : 0), k, 1, n_q, (uint64_t)(blocks + 1) * k, k,
                               s.metric, out_keys, out_ids, out_dist, out_n, stream);

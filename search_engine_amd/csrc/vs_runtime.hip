@@ -423,20 +423,23 @@ int32_t run_many_and_fetch(vs_store* s, const vs::SlabView& v, Workspace* ws, co
     return VS_OK;
 }
 
-// Copies the caller's docid-indexed mask into ws->d_mask, aligned to the store.
-int32_t stage_dense_mask(vs_store* s, Workspace* ws, const uint64_t* mask_words,
-                         uint64_t n_mask_words) {
+// Copies the caller's docid-indexed mask into `d_words` (n_slots / 64 words), aligned to the store.
+int32_t copy_dense_mask(vs_store* s, hipStream_t stream, uint64_t* d_words, const uint64_t* mask_words,
+                        uint64_t n_mask_words) {
     const uint64_t n_words = s->n_slots / 64;
-    if (int32_t rc = grow(&ws->d_mask, &ws->mask_words, (size_t)n_words * 8)) return rc;
     const uint64_t w0 = s->docid_base / 64;
     const uint64_t avail = n_mask_words > w0 ? n_mask_words - w0 : 0;
     const uint64_t ncopy = avail < n_words ? avail : n_words;
     if (ncopy)
-        HIP_TRY(hipMemcpyAsync(ws->d_mask, mask_words + w0, (size_t)ncopy * 8, hipMemcpyHostToDevice,
-                               ws->stream));
-    if (ncopy < n_words)
-        HIP_TRY(hipMemsetAsync(ws->d_mask + ncopy, 0, (size_t)(n_words - ncopy) * 8, ws->stream));
+        HIP_TRY(hipMemcpyAsync(d_words, mask_words + w0, (size_t)ncopy * 8, hipMemcpyHostToDevice, stream));
+    if (ncopy < n_words) HIP_TRY(hipMemsetAsync(d_words + ncopy, 0, (size_t)(n_words - ncopy) * 8, stream));
     return VS_OK;
+}
+// ... into ws->d_mask
+int32_t stage_dense_mask(vs_store* s, Workspace* ws, const uint64_t* mask_words,
+                         uint64_t n_mask_words) {
+    if (int32_t rc = grow(&ws->d_mask, &ws->mask_words, (size_t)(s->n_slots / 64) * 8)) return rc;
+    return copy_dense_mask(s, ws->stream, ws->d_mask, mask_words, n_mask_words);
 }
 
 // Expands a parsed serialised RoaringBitmap into `d_words` (n_slots / 64 words aligned with the store).
@@ -582,6 +585,8 @@ extern "C" int32_t vs_store_create(vs_ctx* ctx, uint16_t store_index, uint32_t d
             return fail(VS_E_INVALID_ARG, "store %u already exists", store_index);
     }
     std::unique_ptr<vs_store> s(new vs_store());
+    static std::atomic<uint64_t> next_serial{1};
+    s->serial = next_serial.fetch_add(1);
     s->ctx = ctx;
     s->index = store_index;
     s->dim = dim;
@@ -1057,7 +1062,7 @@ int32_t mask_new(vs_store* s, vs_mask** out, std::unique_ptr<vs_mask>* m) {
     if (!out) return fail(VS_E_INVALID_ARG, "null out pointer");
     *out = nullptr;
     if (int32_t rc = check_store(s)) return rc;
-    m->reset(new vs_mask{s, nullptr, s->n_slots});
+    m->reset(new vs_mask{s, nullptr, s->n_slots, s->serial});
     if (hipMalloc(&(*m)->d_words, (size_t)(s->n_slots / 64) * 8) != hipSuccess)
         return fail(VS_E_OOM, "cannot allocate a %llu-byte mask", (unsigned long long)(s->n_slots / 8));
     return VS_OK;
@@ -1073,16 +1078,9 @@ extern "C" int32_t vs_mask_create(vs_store* s, const uint64_t* mask_words, uint6
     std::unique_ptr<Workspace> ws;
     int32_t rc = ws_acquire(s->ctx, &ws);
     if (rc == VS_OK) {
-        // stage through the workspace's routine, then keep the words
-        rc = stage_dense_mask(s, ws.get(), mask_words, n_mask_words);
-        if (rc == VS_OK) {
-            rc = [&]() -> int32_t {
-                HIP_TRY(hipMemcpyAsync(m->d_words, ws->d_mask, (size_t)(s->n_slots / 64) * 8,
-                                       hipMemcpyDeviceToDevice, ws->stream));
-                HIP_TRY(hipStreamSynchronize(ws->stream));
-                return VS_OK;
-            }();
-        }
+        rc = copy_dense_mask(s, ws->stream, m->d_words, mask_words, n_mask_words);
+        if (rc == VS_OK && hipStreamSynchronize(ws->stream) != hipSuccess)
+            rc = fail(VS_E_DEVICE, "mask upload failed");
         ws_release(s->ctx, std::move(ws));
     }
     if (rc != VS_OK) {
@@ -1127,12 +1125,17 @@ extern "C" int32_t vs_mask_destroy(vs_mask* m) {
 
 namespace {
 int32_t check_mask(vs_store* s, const vs_mask* mask) {
-    if (mask && mask->store != s) return fail(VS_E_INVALID_ARG, "the mask was created for another store");
+    if (mask && (mask->store != s || mask->store_serial != s->serial))
+        return fail(VS_E_INVALID_ARG, "the mask was created for another store");
     if (mask && mask->n_slots != s->n_slots)
         return fail(VS_E_INVALID_ARG, "the mask was created before the store grew: create it again");
     return VS_OK;
 }
 }  // namespace
+
+extern "C" int32_t vs_mask_fits(vs_store* s, const vs_mask* mask) {
+    return s && mask && mask->store == s && mask->store_serial == s->serial && mask->n_slots == s->n_slots;
+}
 
 extern "C" int32_t vs_search_mask(vs_store* s, const float* query, uint32_t dim, uint32_t k,
                                   const vs_mask* mask, uint32_t* out_ids, float* out_dist,

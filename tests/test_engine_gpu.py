@@ -146,3 +146,59 @@ def test_hybrid_plumbing(gpu_ctx):
     finally:
         for s in stores:
             s.destroy()
+
+
+def test_universe_kept_on_the_device_and_refills(gpu_ctx):
+    """A universe object that comes back: from its second search on a reader names the device copy
+    of its words (vs_search_mask) instead of sending them again; results are those of a search that
+    sends them. And VectorSort driven past its cache: every refill searches what is left (the
+    candidates without the documents handed out so far), until the universe is used up."""
+    from search_engine_amd import _host
+    n_docs, dim, n_stores = 6_000, 64, 2
+    stores, readers = build_world(gpu_ctx, n_docs, dim, n_stores, 11, (CATEGORY + 5) << 8)
+    try:
+        ctx = _host.GpuContext(gpu_ctx.handle.value, {"default": CATEGORY + 5},
+                               oracle.bool_to_mask(np.ones(n_docs, bool)))
+        universe_mask = facet_mask(n_docs, 30)
+        queries = synthetic_vectors(6, dim, 1234).tolist()
+        for skip, limit, dist in ((0, 10, None), (3, 7, (0.5, 0.2))):
+            kept = _host.execute_vector_search_same_universe(ctx, queries, universe_mask, skip, limit, "default", dist)
+            for q, got in zip(queries, kept):
+                assert got == _host.execute_vector_search(ctx, q, universe_mask, skip, limit, "default", dist)
+        # the same through a small (sorted array) universe and through the whole index (a range)
+        few = [5, 77, 4000, 5999]
+        for universe in (few, oracle.bool_to_mask(np.ones(n_docs, bool))):
+            kept = _host.execute_vector_search_same_universe(ctx, queries, universe, 0, 10, "default", None)
+            for q, got in zip(queries, kept):
+                assert got == _host.execute_vector_search(ctx, q, universe, 0, 10, "default", None)
+
+        universe = sorted(np.random.default_rng(3).choice(n_docs, 41, replace=False).tolist())
+        q = queries[0]
+        rule = _host.VectorSort(ctx, q, list(range(n_docs)), 4, "default", None)
+        rule.start_iteration(universe)
+        order = []
+        while True:
+            b = rule.next_bucket()
+            if b is None or not b["candidates"]:
+                break
+            assert len(b["candidates"]) == 1
+            order.append(b["candidates"][0])
+        # what the rule does, replayed on the oracle's readers: a fill asks every store for its nearest
+        # 4 of what is left, hands the documents out in (distance, docid) order -- a document that two
+        # stores returned only once -- and the next fill starts from what is left then
+        left, expect = set(universe), []
+        while left:
+            fill = []
+            for nns in readers:
+                fill += nns(q, 4, left)
+            if not fill:
+                break
+            fill.sort(key=lambda t: (t[1], t[0]))
+            for d, _ in fill:
+                if d in left:
+                    expect.append(d)
+                    left.remove(d)
+        assert order == expect and len(order) > 3 * 4 * n_stores  # several refills happened
+    finally:
+        for s in stores:
+            s.destroy()

@@ -406,3 +406,77 @@ def test_execute_vector_search_batch_equals_single_searches():
     with pytest.raises(host().HostError) as e:
         host().execute_vector_search_batch(ctx, vectors, all_docids, 0, 5, "nope", None)
     assert e.value.args[1] == "InvalidEmbedder"
+
+
+def test_docset_algebra_matches_python_sets():
+    """The three shapes a host-side docid set takes (sorted array up to 4096 documents, the range
+    [0, n) of an index without holes, dense bitmap) against Python sets: every operation the path
+    uses, on every pair of shapes, with the cached cardinality kept honest through modifications."""
+    rng = random.Random(31)
+    n = 9000
+
+    def make(shape):
+        if shape == "array":
+            ids = rng.sample(range(n), rng.randint(0, 300))
+            return ids, set(ids)
+        if shape == "range":
+            m = rng.randint(1, n)
+            return m, set(range(m))
+        if shape == "range-from-ids":  # every docid below m, handed over as a list: recognised as a range
+            m = rng.randint(4097, n)
+            return list(range(m)), set(range(m))
+        if shape == "words":
+            ids = rng.sample(range(n), rng.randint(4100, n))
+            words = np.zeros(-(-n // 64), np.uint64)
+            for d in ids:
+                words[d >> 6] |= np.uint64(1) << np.uint64(d & 63)
+            return words, set(ids)
+        ids = rng.sample(range(n), rng.randint(4100, n - 1))
+        if len(set(ids)) == max(ids) + 1:
+            ids.remove(0)
+        return ids, set(ids)
+
+    expected_repr = {"array": "array", "range": "range", "range-from-ids": "range", "words": "bitmap",
+                     "bitmap": "bitmap"}
+    shapes = list(expected_repr)
+    for sa in shapes:
+        for sb in shapes:
+            for _ in range(3):
+                a, set_a = make(sa)
+                b, set_b = make(sb)
+                script, c, want_effects = [], set(set_a), []
+                for _ in range(12):
+                    op = rng.choice(["insert", "remove", "insert", "remove", "or", "sub"])
+                    if op in ("insert", "remove"):
+                        d = rng.choice([rng.randrange(n + 200), len(c), max(c) if c else 0])
+                        script.append((op, d))
+                        if op == "insert":
+                            want_effects.append(d not in c)
+                            c.add(d)
+                        else:
+                            want_effects.append(d in c)
+                            c.discard(d)
+                    else:
+                        script.append((op,))
+                        c = c | set_b if op == "or" else c - set_b
+                    want_effects.append(len(c))
+                probes = [0, 1, 63, 64, 4095, 4096, n - 1, n, n + 500] + [rng.randrange(n) for _ in range(20)]
+                got = host().docset_probe(a, b, script, probes)
+                assert got["a_repr"] == expected_repr[sa] and got["b_repr"] == expected_repr[sb]
+                assert got["and"] == sorted(set_a & set_b)
+                assert got["and_len"] == got["and_len_again"] == len(set_a & set_b)
+                assert got["or"] == sorted(set_a | set_b)
+                assert got["sub"] == sorted(set_a - set_b) and got["sub_len"] == len(set_a - set_b)
+                assert got["a_after_ops"] == sorted(set_a)
+                assert got["effects"] == want_effects, (sa, sb, script)
+                assert got["c"] == sorted(c) and got["c_empty"] == (not c)
+                assert got["contains"] == [(d in set_a, d in c) for d in probes]
+                words = got["c_words"]
+                assert sorted(64 * i + j for i, w in enumerate(words.tolist()) for j in range(64) if (w >> j) & 1) == sorted(c)
+    # a range over a bitmap that it covers hands the bitmap back as it is
+    words = np.zeros(100, np.uint64)
+    words[3] = 5
+    got = host().docset_probe(6400, words, [], [])
+    assert got["and_repr"] == "bitmap" and got["and"] == [192, 194] and got["and_len"] == 2
+    got = host().docset_probe(193, words, [], [])  # ... and cuts one that reaches beyond it
+    assert got["and"] == [192]

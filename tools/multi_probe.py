@@ -51,7 +51,7 @@ def main():
     queries = torch.randn(args.queries, args.dim, device=dev).cpu().numpy()
     lut = torch.tensor([bin(v).count("1") for v in range(256)], dtype=torch.int64, device=dev)
     for p in [int(x) for x in args.pass_percents.split(",")]:
-        dmask = device_mask(0, n, p, dev)
+        dmask = device_mask(torch, 0, n, p, dev)
         n_pass = int(lut[dmask.view(torch.uint8).long()].sum().item())
         algo = n_pass * (store.row_bytes + (4 if metric == abi.VS_ANGULAR else 0)) + n // 8
         mask = dmask.cpu().numpy().view(np.uint64)

@@ -7,7 +7,7 @@
 Writes profiles/<tag>_kernel_stats.csv (the `--kernel-trace --stats` summary, all
 kernels), profiles/<tag>_scan_by_grid.txt (per-launch durations of the library's
 own kernels, split by grid size) and, when a `--pmc FETCH_SIZE` pass is given,
-profiles/scan_traffic.json: HBM bytes per scan launch = FETCH_SIZE (KiB) x 1024
+profiles/scan_traffic[_<dtype>][_p<percent>].json: HBM bytes per scan launch = FETCH_SIZE (KiB) x 1024
 x 2 — on gfx950 FETCH_SIZE reports half the bytes of a 16-byte-per-lane
 coalesced stream (TCC_EA0_RDREQ counted at 64 B for 128-B requests).
 """
@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--pmc")
     ap.add_argument("--tag", required=True)
     ap.add_argument("--docs", type=int, default=10_000_000)
+    ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--pass-percent", type=int, default=100)
     ap.add_argument("--n-gpus", type=int, default=1)
@@ -70,7 +71,7 @@ def main():
             raise SystemExit("no FETCH_SIZE rows for the scan kernel")
         mean_kib = statistics.mean(vals)
         rec = {
-            "docs": args.docs, "dtype": args.dtype, "pass_percent": args.pass_percent,
+            "docs": args.docs, "dim": args.dim, "dtype": args.dtype, "pass_percent": args.pass_percent,
             "n_gpus": args.n_gpus, "kernel": args.kernel, "launches": len(vals),
             "fetch_size_kib_mean": mean_kib,
             "correction": "x1024 (KiB) x2 (gfx950: FETCH_SIZE counts 128-B requests as 64 B)",
@@ -79,10 +80,12 @@ def main():
         }
         # the headline (p = 100 %) keeps the plain names; other pass rates get a suffix
         sfx = "" if args.pass_percent == 100 else f"_p{args.pass_percent}"
-        rec["source"] = f"rocprofv3 --pmc FETCH_SIZE, profiles/{args.tag}_pmc_fetch_size{sfx}.csv"
-        with open(os.path.join(out, f"scan_traffic{sfx}.json"), "w") as f:
+        fsfx = "" if args.tag.endswith(sfx) else sfx
+        rec["source"] = f"rocprofv3 --pmc FETCH_SIZE, profiles/{args.tag}_pmc_fetch_size{fsfx}.csv"
+        name = "scan_traffic" if args.dtype == "f32" else f"scan_traffic_{args.dtype}"
+        with open(os.path.join(out, f"{name}{sfx}.json"), "w") as f:
             json.dump(rec, f, indent=1)
-        with open(os.path.join(out, f"{args.tag}_pmc_fetch_size{sfx}.csv"), "w") as f:
+        with open(os.path.join(out, f"{args.tag}_pmc_fetch_size{fsfx}.csv"), "w") as f:
             f.write("kernel,launch,FETCH_SIZE_KiB\n")
             for i, v in enumerate(vals):
                 f.write(f"{args.kernel},{i},{v}\n")
