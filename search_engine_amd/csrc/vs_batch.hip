@@ -579,6 +579,15 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
 // the loads removed altogether the ring's loop took as long; with the MFMAs removed it still ran at
 // only 3.5 TB/s. A sub-step of 16 MFMAs per wave is too short to amortise its barrier, its LDS
 // latency and the 100-200 cycles each LDS-DMA instruction takes to issue.
+// On the plain loop, same measurement (cycles per tile and the clock; 3.9 ms for the launch): the
+// kernel as it stands 46 k at 1.8 GHz; without its matrix instructions 50 k at 2.4 GHz (3.2 ms: loads,
+// LDS reads and barriers alone); without loads and LDS reads 30 k at 2.4 GHz (2.0 ms), and without
+// the loads only as long as with them. Requesting the fragments of sub-step kk + 1 before the
+// matrix instructions of kk (3.96 ms), touching a step's lines three steps ahead so that the fetch
+// into LDS hits L2 (4.22 ms), and bringing the rows through two alternating register sets two steps
+// ahead while the queries stay on LDS-DMA (3.98 ms) changed nothing: the loop is not waiting for
+// memory. What remains is the sum of a step's LDS traffic (64 KiB in, 192 KiB out per workgroup) and
+// its 64 matrix instructions per SIMD at the clock the chip holds under both.
 constexpr int S_OFF_NORM = 2 * IMG_BYTES;             // f32[2][256], by tile parity
 constexpr int S_OFF_QUEUE = S_OFF_NORM + 2 * BM * 4;  // u64[2][QCAP]
 constexpr int S_OFF_QCOUNT = S_OFF_QUEUE + 2 * QCAP * 8;
@@ -761,6 +770,9 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
 #ifdef VS_STAMP
     const uint64_t stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
+#ifdef VS_STAMP  // diagnostic build: cycles per tile and the clock they ran at
+    const uint64_t stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (uint32_t j = 0; j < n_mine; ++j) {
         const uint32_t par = j & 1;
         // tile ids two ahead and the next tile's words are requested now and used a tile later
@@ -897,6 +909,13 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
 #pragma unroll
         for (int i = 0; i < 4; ++i) w0[i] = w1[i];
     }
+#ifdef VS_STAMP
+    if (b == 7 && tid == 0) {
+        const uint64_t c = __builtin_amdgcn_s_memtime() - stamp_c0, r = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+        printf("stream: %u tiles, %llu cycles per tile, %.0f MHz\n", n_mine, (unsigned long long)(c / n_mine),
+               (double)c / (double)r * 100.0);
+    }
+#endif
 #ifdef VS_STAMP
     if (b == 7 && tid == 0) {
         const uint64_t c = __builtin_amdgcn_s_memtime() - stamp_c0, r = __builtin_amdgcn_s_memrealtime() - stamp_r0;
