@@ -673,6 +673,42 @@ class GpuReader : public Reader {
         return out;
     }
 
+    std::vector<std::vector<std::pair<DocumentId, float>>> nns_by_vectors_each(
+        const std::vector<std::vector<float>>& targets, size_t count,
+        const std::vector<const DocSet*>& candidates) override {
+        std::vector<std::vector<std::pair<DocumentId, float>>> out(targets.size());
+        if (targets.empty()) return out;
+        if (candidates.size() != targets.size())
+            throw std::logic_error("nns_by_vectors_each: one candidate set per target");
+        if (count > VS_MAX_K)
+            throw Error(Error::ArroyError, "limit " + std::to_string(count) + " exceeds VS_MAX_K");
+        const size_t dim = targets[0].size(), n_q = targets.size(), kk = count ? count : 1;
+        std::vector<float> flat(n_q * dim);
+        for (size_t i = 0; i < n_q; ++i) {
+            if (targets[i].size() != dim) return Reader::nns_by_vectors_each(targets, count, candidates);
+            std::copy(targets[i].begin(), targets[i].end(), flat.begin() + i * dim);
+        }
+        // per query: the device copy of its set if one is kept, else the set's words. Queries whose sets
+        // share their words (copies of one universe object) name the same pointer and share passes.
+        static const uint64_t none = 0;
+        std::vector<const vs_mask*> masks(n_q, nullptr);
+        std::vector<const uint64_t*> words(n_q, nullptr);
+        std::vector<uint64_t> n_words(n_q, 0);
+        for (size_t i = 0; i < n_q; ++i) {
+            masks[i] = kept_mask(*candidates[i]);
+            const std::vector<uint64_t>& w = candidates[i]->words();
+            words[i] = w.empty() ? &none : w.data();  // an empty set is an empty mask, not "no filter"
+            n_words[i] = w.empty() ? 1 : w.size();
+        }
+        std::vector<uint32_t> ids(n_q * kk), n(n_q, 0);
+        std::vector<float> dist(n_q * kk);
+        check(vs_search_batch_masks(store_, flat.data(), (uint32_t)n_q, (uint32_t)dim, (uint32_t)count, words.data(),
+                                    n_words.data(), masks.data(), ids.data(), dist.data(), n.data()));
+        for (size_t i = 0; i < n_q; ++i)
+            for (uint32_t j = 0; j < n[i]; ++j) out[i].emplace_back(ids[i * count + j], dist[i * count + j]);
+        return out;
+    }
+
    private:
     void check(int32_t rc) {
         if (rc == VS_E_DIM_MISMATCH) {
@@ -718,6 +754,13 @@ std::vector<std::vector<std::pair<DocumentId, float>>> Reader::nns_by_vectors(
     const std::vector<std::vector<float>>& targets, size_t count, const DocSet& candidates) {
     std::vector<std::vector<std::pair<DocumentId, float>>> out;
     for (const auto& t : targets) out.push_back(nns_by_vector(t, count, candidates));
+    return out;
+}
+
+std::vector<std::vector<std::pair<DocumentId, float>>> Reader::nns_by_vectors_each(
+    const std::vector<std::vector<float>>& targets, size_t count, const std::vector<const DocSet*>& candidates) {
+    std::vector<std::vector<std::pair<DocumentId, float>>> out;
+    for (size_t i = 0; i < targets.size(); ++i) out.push_back(nns_by_vector(targets[i], count, *candidates.at(i)));
     return out;
 }
 
@@ -876,6 +919,44 @@ std::vector<SearchResult> execute_vector_search_batch(Context& ctx, const std::v
         if (extra_rules)
             for (auto& r : extra_rules()) ranking_rules.push_back(std::move(r));
         BucketSortOutput b = bucket_sort(ranking_rules, limit, skip, universe);
+        SearchResult res;
+        res.candidates = std::move(b.candidates);
+        res.documents_ids = std::move(b.docids);
+        res.document_scores = std::move(b.scores);
+        out.push_back(std::move(res));
+    }
+    return out;
+}
+
+std::vector<SearchResult> execute_vector_search_batch(Context& ctx, const std::vector<std::vector<float>>& vectors,
+                                                      const std::vector<DocSet>& universes, uint64_t skip,
+                                                      uint64_t limit, const std::string& embedder_name,
+                                                      std::optional<DistributionShift> distribution,
+                                                      const ExtraRules& extra_rules) {
+    if (universes.size() != vectors.size())
+        throw std::logic_error("execute_vector_search_batch: one universe per vector");
+    const uint8_t embedder_index = ctx.embedder_category_id(embedder_name);
+    const DocSet all = ctx.all_docids();
+    std::vector<DocSet> first(vectors.size());
+    std::vector<const DocSet*> first_ptrs(vectors.size());
+    for (size_t i = 0; i < vectors.size(); ++i) {
+        first[i] = all & universes[i];
+        first_ptrs[i] = &first[i];
+    }
+    std::vector<std::vector<std::vector<std::pair<DocumentId, float>>>> per_query(vectors.size());
+    for (auto& reader : VectorSort::open_readers(ctx, embedder_index)) {
+        auto r = reader->nns_by_vectors_each(vectors, (size_t)(skip + limit), first_ptrs);
+        for (size_t i = 0; i < vectors.size(); ++i) per_query[i].push_back(std::move(r[i]));
+    }
+    std::vector<SearchResult> out;
+    for (size_t i = 0; i < vectors.size(); ++i) {
+        std::vector<std::unique_ptr<RankingRule>> ranking_rules;
+        auto* vs = new VectorSort(ctx, vectors[i], all, (size_t)(skip + limit), embedder_name, distribution);
+        vs->preload(std::move(per_query[i]));
+        ranking_rules.emplace_back(vs);
+        if (extra_rules)
+            for (auto& r : extra_rules()) ranking_rules.push_back(std::move(r));
+        BucketSortOutput b = bucket_sort(ranking_rules, limit, skip, universes[i]);
         SearchResult res;
         res.candidates = std::move(b.candidates);
         res.documents_ids = std::move(b.docids);

@@ -211,6 +211,10 @@ struct Reader {
     // do better (one pass over the store for all targets) overrides it.
     virtual std::vector<std::vector<std::pair<DocumentId, float>>> nns_by_vectors(
         const std::vector<std::vector<float>>& targets, size_t count, const DocSet& candidates);
+    // ... and with a candidate set PER target (several requests, each with the universe of its own
+    // filter, src/search/search.rs:222-228): result i = nns_by_vector(targets[i], count, *candidates[i]).
+    virtual std::vector<std::vector<std::pair<DocumentId, float>>> nns_by_vectors_each(
+        const std::vector<std::vector<float>>& targets, size_t count, const std::vector<const DocSet*>& candidates);
 };
 
 // The methods of `trait Context` the vector path calls.
@@ -296,6 +300,14 @@ SearchResult execute_vector_search(Context& ctx, const std::vector<float>& vecto
 std::vector<SearchResult> execute_vector_search_batch(Context& ctx, const std::vector<std::vector<float>>& vectors,
                                                       DocSet universe, uint64_t skip, uint64_t limit,
                                                       const std::string& embedder_name,
+                                                      std::optional<DistributionShift> distribution,
+                                                      const ExtraRules& extra_rules = nullptr);
+// ... for several REQUESTS: vector i is searched under universes[i] (one per vector). Each store is
+// still asked once (Reader::nns_by_vectors_each); requests that hand over the same universe object
+// share passes over the rows.
+std::vector<SearchResult> execute_vector_search_batch(Context& ctx, const std::vector<std::vector<float>>& vectors,
+                                                      const std::vector<DocSet>& universes, uint64_t skip,
+                                                      uint64_t limit, const std::string& embedder_name,
                                                       std::optional<DistributionShift> distribution,
                                                       const ExtraRules& extra_rules = nullptr);
 

@@ -463,6 +463,30 @@ PYBIND11_MODULE(_host, m) {
           py::arg("embedder_name"), py::arg("distribution") = py::none(),
           py::arg("extra_rules") = py::none());
 
+    // one universe per vector (several requests in one call); universes[i] may be the same Python
+    // object as universes[j]: those requests then share one C++ set, as a host's filter cache would
+    m.def("execute_vector_search_batch_universes",
+          [](py::object ctx, std::vector<std::vector<float>> vectors, py::list universes, uint64_t skip,
+             uint64_t limit, const std::string& embedder_name, py::object distribution) {
+              std::shared_ptr<Context> c = context_from_py(ctx);
+              std::vector<DocSet> sets;
+              std::vector<PyObject*> seen;
+              for (py::handle u : universes) {
+                  size_t at = seen.size();
+                  for (size_t j = 0; j < seen.size(); ++j)
+                      if (seen[j] == u.ptr()) at = j;
+                  seen.push_back(u.ptr());
+                  sets.push_back(at < sets.size() ? sets[at] : to_docset(py::reinterpret_borrow<py::object>(u)));
+              }
+              py::list out;
+              for (const SearchResult& r : execute_vector_search_batch(*c, vectors, sets, skip, limit, embedder_name,
+                                                                       distribution_from_py(distribution)))
+                  out.append(result_to_py(r));
+              return out;
+          },
+          py::arg("ctx"), py::arg("vectors"), py::arg("universes"), py::arg("skip"), py::arg("limit"),
+          py::arg("embedder_name"), py::arg("distribution") = py::none());
+
     // execute_vector_search once per vector with ONE universe object, as a host does that keeps
     // the bitmap of a facet filter across requests (what a reader left with the set stays with it)
     m.def("execute_vector_search_same_universe",

@@ -202,3 +202,27 @@ def test_universe_kept_on_the_device_and_refills(gpu_ctx):
     finally:
         for s in stores:
             s.destroy()
+
+
+def test_vector_search_batch_with_a_universe_per_request(gpu_ctx):
+    """B requests with B filters in one call (vs_search_batch_masks under the host mirror): result i
+    equals the single search of vector i under universe i; requests that hand over the same universe
+    object share passes, and on a second call their universe is already on the device."""
+    from search_engine_amd import _host
+    n_docs, dim, n_stores = 5_000, 96, 2
+    stores, _ = build_world(gpu_ctx, n_docs, dim, n_stores, 21, (CATEGORY + 6) << 8)
+    try:
+        ctx = _host.GpuContext(gpu_ctx.handle.value, {"default": CATEGORY + 6},
+                               oracle.bool_to_mask(np.ones(n_docs, bool)))
+        queries = synthetic_vectors(9, dim, 4321).tolist()
+        shared = facet_mask(n_docs, 20)
+        universes = [shared, facet_mask(n_docs, 50), [3, 4, 4999], shared, [], oracle.bool_to_mask(np.ones(n_docs, bool)),
+                     shared, facet_mask(n_docs, 1), list(range(100, 200))]
+        for skip, limit, dist in ((0, 10, None), (4, 6, (0.5, 0.2))):
+            for _ in range(2):
+                got = _host.execute_vector_search_batch_universes(ctx, queries, universes, skip, limit, "default", dist)
+                for q, u, g in zip(queries, universes, got):
+                    assert g == _host.execute_vector_search(ctx, q, u, skip, limit, "default", dist)
+    finally:
+        for s in stores:
+            s.destroy()

@@ -480,3 +480,21 @@ def test_docset_algebra_matches_python_sets():
     assert got["and_repr"] == "bitmap" and got["and"] == [192, 194] and got["and_len"] == 2
     got = host().docset_probe(193, words, [], [])  # ... and cuts one that reaches beyond it
     assert got["and"] == [192]
+
+
+def test_execute_vector_search_batch_with_a_universe_per_request():
+    """Several requests in one call, each under the universe of its own filter: result i is
+    execute_vector_search of vector i under universe i (fake readers: the default loop)."""
+    rng = np.random.default_rng(12)
+    n_docs, dim, n_stores = 90, 5, 2
+    stores, _ = make_random_world(rng, n_docs, dim, n_stores)
+    all_docids = list(range(n_docs))
+    ctx = FakeContext(stores, all_docids)
+    vectors = rng.standard_normal((6, dim)).astype(np.float32).tolist()
+    shared = [d for d in all_docids if d % 3]
+    universes = [all_docids, shared, [7], [], shared, [d for d in all_docids if d > 40]]
+    for skip, limit, dist in ((0, 10, None), (2, 5, (0.6, 0.2)), (0, 0, None)):
+        got = host().execute_vector_search_batch_universes(ctx, vectors, universes, skip, limit, "manual", dist)
+        assert len(got) == len(vectors)
+        for v, u, g in zip(vectors, universes, got):
+            assert g == host().execute_vector_search(ctx, v, u, skip, limit, "manual", dist)
