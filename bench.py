@@ -194,7 +194,25 @@ def main():
         uid.copy_(torch.frombuffer(bytearray(abi.group_unique_id()), dtype=torch.uint8))
     if use_dist:
         dist.broadcast(uid, 0)
-    group = abi.Group(ctx, rank, world, bytes(uid.cpu().numpy().tobytes()))
+    # If the library's communicator cannot be made on some rank, every rank takes the same exchange
+    # through torch.distributed instead (the same kernels; `config.collective` says which one ran).
+    group, group_error = None, None
+    try:
+        if os.environ.get("VS_BENCH_NO_GROUP") == "1":  # rehearsal of the other exchange; never set by the driver
+            raise RuntimeError("VS_BENCH_NO_GROUP=1")
+        group = abi.Group(ctx, rank, world, bytes(uid.cpu().numpy().tobytes()))
+    except Exception as exc:  # reported below, never silent
+        group_error = repr(exc)
+    if use_dist:
+        ok = torch.tensor([1 if group is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and group is not None:
+            group.destroy()
+            group = None
+    if group is None and not use_dist:
+        raise SystemExit(f"vs_group_create failed: {group_error}")
+    if group is None and rank == 0:
+        print(f"bench: vs_group_create failed ({group_error}); exchanging through torch.distributed", file=sys.stderr)
 
     dim, k = args.dim, args.k
     bin1 = args.dtype == "bin1"
@@ -244,13 +262,31 @@ def main():
     out_dist = torch.empty(n_q * k, dtype=torch.float32, device=dev)
     out_n = torch.empty(n_q, dtype=torch.int32, device=dev)
 
+    if group is None:  # the exchange outside the library: local keys, all_gather_into_tensor, one merge launch
+        ws = torch.empty(max(store.workspace_bytes(k), store.batch_workspace_bytes(k) if batched else 0),
+                         dtype=torch.uint8, device=dev)
+        local_keys = torch.empty(n_q * k, dtype=torch.int64, device=dev)
+        all_keys = torch.empty(world * n_q * k, dtype=torch.int64, device=dev)
+
     def step(i, mask, events=None):
         q = queries[(i * n_q) % (1024 - n_q + 1):]
         if events is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        group.search_sharded_device(store, q.data_ptr(), n_q, dim, k, mask.data_ptr(), flags,
-                                    out_ids.data_ptr(), out_dist.data_ptr(), out_n.data_ptr(), stream)
+        if group is not None:
+            group.search_sharded_device(store, q.data_ptr(), n_q, dim, k, mask.data_ptr(), flags,
+                                        out_ids.data_ptr(), out_dist.data_ptr(), out_n.data_ptr(), stream)
+        else:
+            if batched:
+                store.search_batch_device(q.data_ptr(), n_q, dim, k, mask.data_ptr(), ws.data_ptr(),
+                                          local_keys.data_ptr(), stream)
+            else:
+                for j in range(n_q):
+                    store.search_device(q[j].data_ptr(), dim, k, mask.data_ptr(), ws.data_ptr(),
+                                        local_keys.data_ptr() + 8 * k * j, stream)
+            dist.all_gather_into_tensor(all_keys, local_keys)
+            ctx.merge_topk_batch_device(all_keys.data_ptr(), world, n_q * k, n_q, k, k, metric,
+                                        out_ids.data_ptr(), out_dist.data_ptr(), out_n.data_ptr(), stream)
         if events is not None:
             e1.record()
             events.append((e0, e1))
@@ -354,7 +390,9 @@ def main():
                 "docs": args.docs, "dim": dim, "k": k, "pass_percent": args.pass_percent, "queries_per_step": n_q,
                 "parallelism": f"docid-range shards x{world}, one RCCL all-gather of top-k keys per step "
                                f"(vs_search_sharded_device)",
-                "ranks_in_group": group.world,
+                "ranks_in_group": group.world if group is not None else world,
+                "collective": "vs_group (RCCL inside libvs_amd.so)" if group is not None
+                              else "torch.distributed all_gather_into_tensor (vs_group_create failed)",
             },
         }
         if not batched:
@@ -402,7 +440,8 @@ def main():
         line["cpu_baseline"] = cpu
         line["sweep"] = sweep
         print(json.dumps(line), flush=True)
-    group.destroy()
+    if group is not None:
+        group.destroy()
     store.destroy()
     ctx.close()
     if use_dist:

@@ -16,11 +16,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def bench(*flags, force_dist):
+def bench(*flags, force_dist, no_group=False):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
     env.pop("VS_BENCH_FORCE_DIST", None)
+    env.pop("VS_BENCH_NO_GROUP", None)
     if force_dist:
         env["VS_BENCH_FORCE_DIST"] = "1"
+    if no_group:
+        env["VS_BENCH_NO_GROUP"] = "1"
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
                           "--no-cpu-baseline", "--sweep", "", *flags],
                          env=env, capture_output=True, text=True, timeout=240)
@@ -60,3 +63,16 @@ def test_batched_bench_under_a_one_rank_rccl_group():
 def test_shared_pass_f32_bench_line_stays_below_the_roofline():
     line = bench("--docs", "400000", "--batch-queries", "64", "--pass-percent", "10", force_dist=False)
     assert 0 < line["roofline"]["frac"] < 1 and line["roofline"]["passes_per_step"] == 2
+
+
+def test_the_exchange_through_torch_distributed_when_the_group_cannot_be_made():
+    """bench.py's other exchange (local keys, all_gather_into_tensor, one merge launch), taken by every
+    rank when vs_group_create fails on any: the same accounting, and the line says which one ran."""
+    for flags in (("--docs", "300000", "--pass-percent", "50"),
+                  ("--docs", "200000", "--dtype", "bf16", "--batch-queries", "256")):
+        via_group = bench(*flags, force_dist=True)
+        via_torch = bench(*flags, force_dist=True, no_group=True)
+        assert via_group["config"]["collective"].startswith("vs_group")
+        assert via_torch["config"]["collective"].startswith("torch.distributed")
+        assert via_torch["value"] > 0 and 0 < via_torch["roofline"]["frac"] < 1
+        assert via_torch["roofline"]["algorithmic_bytes_per_launch"] == via_group["roofline"]["algorithmic_bytes_per_launch"]
