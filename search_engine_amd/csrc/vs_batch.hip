@@ -579,15 +579,17 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
 // the loads removed altogether the ring's loop took as long; with the MFMAs removed it still ran at
 // only 3.5 TB/s. A sub-step of 16 MFMAs per wave is too short to amortise its barrier, its LDS
 // latency and the 100-200 cycles each LDS-DMA instruction takes to issue.
-// On the plain loop, same measurement (cycles per tile and the clock; 3.9 ms for the launch): the
-// kernel as it stands 46 k at 1.8 GHz; without its matrix instructions 50 k at 2.4 GHz (3.2 ms: loads,
-// LDS reads and barriers alone); without loads and LDS reads 30 k at 2.4 GHz (2.0 ms), and without
-// the loads only as long as with them. Requesting the fragments of sub-step kk + 1 before the
-// matrix instructions of kk (3.96 ms), touching a step's lines three steps ahead so that the fetch
-// into LDS hits L2 (4.22 ms), and bringing the rows through two alternating register sets two steps
-// ahead while the queries stay on LDS-DMA (3.98 ms) changed nothing: the loop is not waiting for
-// memory. What remains is the sum of a step's LDS traffic (64 KiB in, 192 KiB out per workgroup) and
-// its 64 matrix instructions per SIMD at the clock the chip holds under both.
+// On the plain loop with its barrier BETWEEN two steps (cycles per tile and the clock; 3.93 ms for the
+// launch): whole kernel 46 k at 1.8 GHz; loads and barriers alone 45 k at 2.4 GHz; LDS reads and
+// barriers alone 13 k; matrix instructions and barriers alone 29 k (24.6 k of them the instructions);
+// matrix instructions + LDS reads 34 k WITHOUT the barrier and 49 k with it. So it was neither memory
+// nor LDS bandwidth but the barrier's place: behind it all eight waves first waited for their
+// fragments with the matrix pipe idle. Giving memory more time changed nothing while that stood
+// (fragments of sub-step kk + 1 requested before the matrix instructions of kk: 3.96 ms; a step's
+// lines touched three steps ahead so that the LDS-DMA hits L2: 4.22 ms; rows through two alternating
+// register sets two steps ahead: 3.98 ms, although the loads alone then took 38 k instead of 45 k).
+// Rotated as below: 39 k cycles at 1.62 GHz, 3.64 ms -- the clock gives back part of what the cycles
+// gain (the chip is at its power limit with the matrix pipe 63 % busy).
 constexpr int S_OFF_NORM = 2 * IMG_BYTES;             // f32[2][256], by tile parity
 constexpr int S_OFF_QUEUE = S_OFF_NORM + 2 * BM * 4;  // u64[2][QCAP]
 constexpr int S_OFF_QCOUNT = S_OFF_QUEUE + 2 * QCAP * 8;
@@ -738,11 +740,47 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
     uint64_t w0[4];
     words_of(t0, w0);
     if (wv == 7) issue_norms(t0, 0);
-    uint32_t image = 0;  // the image the step about to be multiplied lands in
+    uint32_t image = 0;  // the image the step about to be multiplied lies in
     load_step(t0, 0, image);
 
     const uint32_t frag_a = swz(wm * 64 + r32, half), frag_b = IMG_B + swz(wn * 128 + r32, half);
     uint32_t t_prev = TILE_NONE;
+
+    // The loop is rotated by a quarter step: a step's one barrier stands before the matrix
+    // instructions of its LAST sub-step, whose fragments are in registers by then. Behind the barrier
+    // a wave requests the first fragments of the NEXT step (its image is complete: that is what the
+    // barrier says) and the rows of the step after that (into the image everybody has just finished
+    // reading), and then still has eight matrix instructions to issue while those reads fly. With the
+    // barrier between two steps instead, every step began with all eight waves waiting for LDS and
+    // the matrix pipe idle: 49 k cycles per tile against 34 k without any barrier (loads left out).
+    bf16x8 fa[2][2], fb[2][4];
+    auto read_frags = [&](const unsigned char* img, int kk, bf16x8 (&xa)[2], bf16x8 (&xb)[4]) {
+        uint32_t fo_a = frag_a ^ ((uint32_t)kk << 5), fo_b = frag_b ^ ((uint32_t)kk << 5);
+        asm volatile("" : "+v"(fo_a), "+v"(fo_b));  // recompute per step, do not keep 8 addresses live
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#ifdef VS_ABL_NOLDSREAD
+            xa[m] = __builtin_bit_cast(bf16x8, u32x4{fo_a, 1u, 2u, 3u});
+#else
+            xa[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + m * 32 * 128 + fo_a));
+#endif
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#ifdef VS_ABL_NOLDSREAD
+            xb[n] = __builtin_bit_cast(bf16x8, u32x4{fo_b, 1u, 2u, 3u});
+#else
+            xb[n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + n * 32 * 128 + fo_b));
+#endif
+    };
+    // step 0 is complete and visible; its first fragments and the rows of step 1 are requested
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    read_frags(lds, 0, fa[0], fb[0]);
+    {
+        const uint32_t t_1 = 1 < KS ? t0 : t1, k_1 = 1 < KS ? 1u : 0u;
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) load_piece(t_1, k_1, 1, pc);
+    }
 
     // appends the queue of tile `t` (parity pp) to this workgroup's region; wave 0 only, which
     // keeps the region's fill in `n_out`
@@ -767,9 +805,6 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
         if (lane == 0) qcount[pp] = 0;
     };
 
-#ifdef VS_STAMP
-    const uint64_t stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
 #ifdef VS_STAMP  // diagnostic build: cycles per tile and the clock they ran at
     const uint64_t stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -788,72 +823,86 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
 
+        // the tile's own barrier: the previous tile's survivors are queued, this tile's norms have landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid < (uint32_t)BM) {
+            // rows that are not candidates get a NaN norm: their t is NaN, which the running
+            // maximum ignores
+            const bool is_cand = (w0[tid >> 6] >> (tid & 63)) & 1;  // w0[] index is wave-uniform
+            const float pn = snorm[par * BM + tid];
+            if (is_cand && !(pn < __builtin_inff())) *a.overflow = 1u;
+            if (!is_cand) snorm[par * BM + tid] = __builtin_nanf("");
+        }
+        if (wv == 0 && j > 0) flush(t_prev, par ^ 1u);
+        if (wv == 7) issue_norms(t1, par ^ 1u);
+
         for (uint32_t ks = 0; ks < KS; ++ks) {
-            // my pieces of this step are in LDS ...
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            // ... everyone's are; the previous step's readers are done with the other image
-#ifndef VS_ABL_NOBARRIER
-            __builtin_amdgcn_s_barrier();
-#endif
-            if (ks == 0) {
-                if (tid < (uint32_t)BM) {
-                    // rows that are not candidates get a NaN norm: their t is NaN, which the running
-                    // maximum ignores
-                    const bool is_cand = (w0[tid >> 6] >> (tid & 63)) & 1;  // w0[] index is wave-uniform
-                    const float pn = snorm[par * BM + tid];
-                    if (is_cand && !(pn < __builtin_inff())) *a.overflow = 1u;
-                    if (!is_cand) snorm[par * BM + tid] = __builtin_nanf("");
-                }
-                if (wv == 0 && j > 0) flush(t_prev, par ^ 1u);
-                if (wv == 7) issue_norms(t1, par ^ 1u);
-            }
             const unsigned char* img = lds + image * IMG_BYTES;
-            image ^= 1u;
-            const bool last = ks + 1 == KS;
-            const uint32_t nt = last ? t1 : t0, nks = last ? 0 : ks + 1;  // (past the last tile: zeros)
-            // The fragments of sub-step kk + 1 are requested before the matrix instructions of kk:
-            // the compiler may not move an LDS read above an LDS-DMA (which writes LDS), and left to
-            // itself the scheduler sinks each read to its first use.
-            bf16x8 fa[2][2], fb[2][4];
-            auto read_frags = [&](int kk, bf16x8 (&xa)[2], bf16x8 (&xb)[4]) {
-                uint32_t fo_a = frag_a ^ ((uint32_t)kk << 5), fo_b = frag_b ^ ((uint32_t)kk << 5);
-                asm volatile("" : "+v"(fo_a), "+v"(fo_b));  // recompute per step, do not keep 8 addresses live
+            const uint32_t other = image ^ 1u;
+            // (tile, step) of the next step and of the one after it (past the last tile: zeros)
+            const uint32_t t_1 = ks + 1 < KS ? t0 : t1, k_1 = ks + 1 < KS ? ks + 1 : 0;
+            uint32_t t_2 = t0, k_2 = ks + 2;
+            if (k_2 >= KS) {
+                k_2 -= KS;
+                t_2 = t1;
+                if (k_2 >= KS) {  // one-step tiles
+                    k_2 -= KS;
+                    t_2 = t2;
+                }
+            }
+            auto multiply = [&](const bf16x8 (&xa)[2], const bf16x8 (&xb)[4]) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
-#ifdef VS_ABL_NOLDSREAD
-                    xa[m] = __builtin_bit_cast(bf16x8, u32x4{fo_a, 1u, 2u, 3u});
-#else
-                    xa[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + m * 32 * 128 + fo_a));
-#endif
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-#ifdef VS_ABL_NOLDSREAD
-                    xb[n] = __builtin_bit_cast(bf16x8, u32x4{fo_b, 1u, 2u, 3u});
-#else
-                    xb[n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + n * 32 * 128 + fo_b));
-#endif
-            };
-            read_frags(0, fa[0], fb[0]);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int cur = kk & 1;
-                if (kk < 3) read_frags(kk + 1, fa[cur ^ 1], fb[cur ^ 1]);
-                __builtin_amdgcn_sched_barrier(0);  // (the scheduler would sink the reads to their first use)
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-#ifndef VS_ABL_NOLOAD
-                    load_piece(nt, nks, image, kk * 2 + m);
-#endif
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
 #ifdef VS_ABL_NOMFMA
-                        asm volatile("" ::"v"(fa[cur][m]), "v"(fb[cur][n]));
+                        asm volatile("" ::"v"(xa[m]), "v"(xb[n]));
 #else
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][m], fb[cur][n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[m], xb[n], acc[m][n], 0, 0, 0);
 #endif
-                }
-            }
+            };
+            // sub-steps 0 .. 2: the fragments of the next one first (the scheduler would sink them to
+            // their first use), the next step's query pieces in between
+            // (this step's first fragments, requested eight matrix instructions ago: waiting for them here,
+            // before anything else is requested, keeps the compiler from waiting for everything later)
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+            read_frags(img, 1, fa[1], fb[1]);
+            __builtin_amdgcn_sched_barrier(0);
+#ifndef VS_ABL_NOLOAD
+            load_piece(t_1, k_1, other, 4);
+            load_piece(t_1, k_1, other, 5);
+#endif
+            multiply(fa[0], fb[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(img, 2, fa[0], fb[0]);
+            __builtin_amdgcn_sched_barrier(0);
+#ifndef VS_ABL_NOLOAD
+            load_piece(t_1, k_1, other, 6);
+            load_piece(t_1, k_1, other, 7);
+#endif
+            multiply(fa[1], fb[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(img, 3, fa[1], fb[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(fa[0], fb[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            // my pieces of the next step are in LDS, my reads of this one are done ...
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // ... everyone's are
+#ifndef VS_ABL_NOBARRIER
+            __builtin_amdgcn_s_barrier();
+#endif
+            read_frags(lds + other * IMG_BYTES, 0, fa[0], fb[0]);
+            __builtin_amdgcn_sched_barrier(0);
+#ifndef VS_ABL_NOLOAD
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) load_piece(t_2, k_2, image, pc);
+#endif
+            multiply(fa[1], fb[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            image = other;
         }
 
         // ---- register test: t = score - |row| * c2[query]; per query column the largest t.
@@ -879,7 +928,11 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
+#ifdef VS_ABL_NOHITS
+                    const bool lane_hit = false && tmax[m][n] >= 0.0f;
+#else
                     const bool lane_hit = tmax[m][n] >= 0.0f && col_ok[n];
+#endif
                     if (__ballot(lane_hit) == 0) continue;  // wave-uniform, the common case
                     uint32_t hit = 0;
                     if (lane_hit) {
@@ -909,13 +962,6 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
 #pragma unroll
         for (int i = 0; i < 4; ++i) w0[i] = w1[i];
     }
-#ifdef VS_STAMP
-    if (b == 7 && tid == 0) {
-        const uint64_t c = __builtin_amdgcn_s_memtime() - stamp_c0, r = __builtin_amdgcn_s_memrealtime() - stamp_r0;
-        printf("stream: %u tiles, %llu cycles per tile, %.0f MHz\n", n_mine, (unsigned long long)(c / n_mine),
-               (double)c / (double)r * 100.0);
-    }
-#endif
 #ifdef VS_STAMP
     if (b == 7 && tid == 0) {
         const uint64_t c = __builtin_amdgcn_s_memtime() - stamp_c0, r = __builtin_amdgcn_s_memrealtime() - stamp_r0;

@@ -88,6 +88,25 @@ def test_batch_parity_filters_and_holes(gpu_ctx, pass_percent):
         store.destroy()
 
 
+@pytest.mark.parametrize("dim", [100, 160])
+def test_streaming_pass_with_two_and_three_step_tiles(gpu_ctx, dim):
+    """The streaming second pass requests a step's rows two steps ahead, across tile boundaries: tiles
+    of two steps (100 dimensions) and of three (160), next to the one-step tiles of the test below."""
+    n = 256 * 256 * 2 + 64 * 5
+    vectors = synthetic_vectors(n, dim, 0x51DE + dim)
+    queries = synthetic_vectors(19, dim, 0x51DF + dim)
+    rng = np.random.default_rng(dim)
+    for j in range(queries.shape[0]):
+        for pos in rng.choice(n, 4, replace=False):
+            vectors[pos] = queries[j] + 0.05 * rng.standard_normal(dim).astype(np.float32)
+    store = make_bf16_store(gpu_ctx, vectors)
+    try:
+        check_batch(store, vectors, queries, 10, facet_mask(n, 40))
+        check_batch(store, vectors, queries, 10, None)
+    finally:
+        store.destroy()
+
+
 @pytest.mark.parametrize("awkward", [True, False])
 @pytest.mark.parametrize("pass_percent,k", [(None, 10), (3, 10), (50, 32), ("top third", 10)])
 def test_batch_parity_beyond_the_sample_pass(gpu_ctx, pass_percent, k, awkward):
