@@ -37,7 +37,7 @@ def main():
     store.seal()
     queries = np.random.default_rng(42).standard_normal((args.reps, args.dim), dtype=np.float32)
     for p in (100, 10, 1):
-        mask = device_mask(0, n, p, dev).cpu().numpy().view(np.uint64)
+        mask = device_mask(torch, 0, n, p, dev).cpu().numpy().view(np.uint64)
         blob = abi.mask_to_roaring(mask)
         variants = {"dense mask": lambda q: store.search(q, args.k, mask),
                     "roaring": lambda q: store.search_roaring(q, args.k, blob)}

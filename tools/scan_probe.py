@@ -59,7 +59,7 @@ def main():
     variants = [tuple(int(x) for x in v.split(":")) for v in args.variants.split(",")]
     lut = torch.tensor([bin(v).count("1") for v in range(256)], dtype=torch.int64, device=dev)
     for p in [int(x) for x in args.pass_percents.split(",")]:
-        mask = device_mask(0, n, p, dev)
+        mask = device_mask(torch, 0, n, p, dev)
         n_pass = int(lut[mask.view(torch.uint8).long()].sum().item())
         algo = n_pass * (store.row_bytes + (4 if args.metric in ('', 'angular') and not binary else 0)) + n // 8
         times = {v: [] for v in variants}
