@@ -374,10 +374,11 @@ int32_t vs_group_destroy(vs_group* g);
  * leaves the GLOBAL top-k of each on every rank: local scans, ONE all-gather of
  * the shard-local keys (8 * k * n_q bytes per rank) over xGMI, one merge launch.
  * Collective: every rank of the group calls it with the same n_q, k and flags,
- * in the same order. Asynchronous on `hip_stream`; a group's calls must be
- * ordered on the device (one stream, or the caller's own events): its buffers
- * are reused from call to call, and are grown (an allocation) the first time a
- * larger n_q * k comes along.
+ * in the same order. Asynchronous on `hip_stream`. A group's buffers are reused
+ * from call to call, so its searches run one after the other on the device as
+ * well: a call on another stream than the group's previous one first makes its
+ * stream wait for that one's end. The buffers are grown (an allocation) the
+ * first time a larger n_q * k comes along.
  *   d_queries:    f32 [n_q][dim] in device memory (VS_BIN1: n_q packed queries
  *                 of vs_store_row_bytes bytes), the same on every rank
  *   d_mask_words: this rank's candidate words, aligned to its store as in

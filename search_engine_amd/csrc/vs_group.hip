@@ -69,6 +69,11 @@ struct vs_group {
     size_t local_bytes = 0;
     uint64_t* d_gather = nullptr;  // every shard's keys [world][n_q][k]
     size_t gather_bytes = 0;
+    // the buffers above serve one search at a time ON THE DEVICE too: a search on another stream than
+    // the last one first waits for that one's end
+    hipEvent_t last_done = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool has_last = false;
 };
 
 extern "C" int32_t vs_group_unique_id(uint8_t* out) {
@@ -96,7 +101,14 @@ extern "C" int32_t vs_group_create(vs_ctx* ctx, int32_t rank, int32_t world, con
     g->world = world;
     ncclUniqueId id;
     memcpy(id.internal, unique_id, VS_GROUP_ID_BYTES);
-    RCCL_TRY(api, api->CommInitRank(&g->comm, world, id, rank));
+    HIP_TRY(hipEventCreateWithFlags(&g->last_done, hipEventDisableTiming));
+    {
+        const ncclResult_t r = api->CommInitRank(&g->comm, world, id, rank);
+        if (r != ncclSuccess) {
+            (void)hipEventDestroy(g->last_done);
+            return fail(VS_E_DEVICE, "ncclCommInitRank failed: %s", api->GetErrorString(r));
+        }
+    }
     *out = g.release();
     return VS_OK;
 }
@@ -109,6 +121,7 @@ extern "C" int32_t vs_group_destroy(vs_group* g) {
     if (g->d_partial) (void)hipFree(g->d_partial);
     if (g->d_local) (void)hipFree(g->d_local);
     if (g->d_gather) (void)hipFree(g->d_gather);
+    if (g->last_done) (void)hipEventDestroy(g->last_done);
     delete g;
     return VS_OK;
 }
@@ -129,6 +142,7 @@ extern "C" int32_t vs_search_sharded_device(vs_group* g, vs_store* s, const void
     const bool gather = g->world > 1 || (flags & VS_SHARDED_ALWAYS_GATHER);
     const vs::ScanTuning t = vsrt::tuning_of(s->ctx);
     std::lock_guard<std::mutex> lock(g->mu);
+    if (g->has_last && g->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, g->last_done, 0));
     vsrt::Snapshot snap;
     vsrt::snapshot_begin(s, &snap);
     const vs::SlabView& v = snap.v;
@@ -177,5 +191,9 @@ extern "C" int32_t vs_search_sharded_device(vs_group* g, vs_store* s, const void
     };
     const int32_t rc = body();
     const int32_t rc2 = vsrt::snapshot_end_async(s, &snap, stream, true);
+    if (hipEventRecord(g->last_done, stream) == hipSuccess) {
+        g->last_stream = stream;
+        g->has_last = true;
+    }
     return rc ? rc : rc2;
 }

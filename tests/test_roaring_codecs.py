@@ -93,8 +93,10 @@ def test_cbo_verify_threshold():
 
 
 def test_cbo_merge_scenarios_decode():
-    """merge_cbo_roaring_bitmaps: the small inputs (raw lists) and the medium result
-    (0..23, roaring form) decode to the expected sets."""
+    """The bitmaps that the reference's merge_cbo_roaring_bitmaps test feeds in and expects out
+    (small ones as raw integer lists, the 0..23 result in roaring form) encode and decode to the same
+    sets here. Only the codec's two forms are checked: CboRoaringBitmapCodec::merge_into itself
+    (cbo_roaring_bitmap_codec.rs:60-...) is off the search path and is not restated."""
     from search_engine_amd import abi
     for ids in ([1, 2, 3], [2, 3, 4], [4, 5], [1, 2], list(range(7, 23)), list(range(23))):
         blob = fmt.cbo_serialize(ids)
