@@ -96,6 +96,21 @@ def launch_ranks(args):
     return subprocess.run(cmd, env=env).returncode
 
 
+class stdout_to_stderr:
+    """RCCL greets on stdout when its first communicator is made; this program's stdout carries one
+    JSON line and nothing else, so file descriptor 1 points at stderr while communicators are made."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def shard_of(rank, world, docs):
     """Contiguous docid range of `rank`, boundaries on multiples of 64: (first docid, count)."""
     from search_engine_amd.sharded import shard_range
@@ -182,7 +197,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        with stdout_to_stderr():
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.barrier()  # (makes the communicator now, not inside the first timed collective)
 
     from search_engine_amd import abi
 
@@ -191,7 +208,8 @@ def main():
     # process group) hands it round
     uid = torch.zeros(abi.VS_GROUP_ID_BYTES, dtype=torch.uint8, device=dev)
     if rank == 0:
-        uid.copy_(torch.frombuffer(bytearray(abi.group_unique_id()), dtype=torch.uint8))
+        with stdout_to_stderr():
+            uid.copy_(torch.frombuffer(bytearray(abi.group_unique_id()), dtype=torch.uint8))
     if use_dist:
         dist.broadcast(uid, 0)
     # If the library's communicator cannot be made on some rank, every rank takes the same exchange
@@ -200,7 +218,8 @@ def main():
     try:
         if os.environ.get("VS_BENCH_NO_GROUP") == "1":  # rehearsal of the other exchange; never set by the driver
             raise RuntimeError("VS_BENCH_NO_GROUP=1")
-        group = abi.Group(ctx, rank, world, bytes(uid.cpu().numpy().tobytes()))
+        with stdout_to_stderr():
+            group = abi.Group(ctx, rank, world, bytes(uid.cpu().numpy().tobytes()))
     except Exception as exc:  # reported below, never silent
         group_error = repr(exc)
     if use_dist:

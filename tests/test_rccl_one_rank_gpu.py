@@ -28,8 +28,8 @@ def bench(*flags, force_dist, no_group=False):
                           "--no-cpu-baseline", "--sweep", "", *flags],
                          env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out.stdout
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout  # one JSON line and nothing else on stdout
     return json.loads(lines[0])
 
 
