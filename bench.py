@@ -503,7 +503,7 @@ def cpu_baseline(torch, np, sample, queries, args, dim, k):
         while True:
             _, _, _, used = oracle.nns_batch_mt(rows, q, k, n_threads=threads, norms=norms)
             reps += 1
-            if time.perf_counter() - t0 > 10.0 or reps >= 50:
+            if time.perf_counter() - t0 > 10.0 or reps >= 400:
                 break
         dt = time.perf_counter() - t0
         t1 = time.perf_counter()
