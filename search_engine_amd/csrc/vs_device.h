@@ -177,6 +177,13 @@ struct WaveTopK {
     bool in_regs;
     uint64_t lo, hi;  // entries lane and 64 + lane
     uint64_t tau;
+    // Batched insertion (register lists with a larger k, where one insert costs a few hundred cycles
+    // and a scan under a filter makes hundreds of them per wave: a wave that sees n candidates inserts
+    // about k (1 + ln(n / k)) times): candidates below tau are parked in a 128-entry LDS buffer and,
+    // 65 or more at a time, sorted and merged into the list in one go. tau moves only then, so a few
+    // more candidates get parked than an insert at a time would have admitted; the list is the same.
+    uint64_t* parked = nullptr;
+    uint32_t n_parked = 0;  // wave-uniform
 
     __device__ __forceinline__ void init(uint64_t* lds_, int k_, int lane_) {
         lds = lds_;
@@ -205,6 +212,42 @@ struct WaveTopK {
         } else {
             tau = list_insert(lds, k, key, lane);
         }
+    }
+    __device__ __forceinline__ void park_in(uint64_t* buffer128) {
+        parked = buffer128;
+        n_parked = 0;
+    }
+    __device__ __forceinline__ bool parks() const { return parked != nullptr; }
+    // Every lane calls; lanes with `mine` hold a candidate `key` < tau.
+    __device__ __forceinline__ void park(bool mine, uint64_t key) {
+        const uint64_t m = __ballot(mine);
+        if (!m) return;
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+        if (mine) parked[n_parked + below] = key;  // at most 64 parked before, at most 64 new: 128 fit
+        n_parked += (uint32_t)__popcll(m);
+        wave_lds_fence();
+        if (n_parked > 64) merge_parked();
+    }
+    __device__ __forceinline__ void merge_parked() {
+        if (!n_parked) return;
+        uint64_t a = (uint32_t)lane < n_parked ? parked[lane] : KEY_NONE;
+        uint64_t b = (uint32_t)lane + 64 < n_parked ? parked[lane + 64] : KEY_NONE;
+        wave_lds_fence();
+        n_parked = 0;
+        bitonic_sort128(a, b, lane);
+        // C[i] = min(list[i], parked[127 - i]) holds the 128 smallest of both and is bitonic (as in
+        // absorb): entry 127 - i is `b` of lane 63 - i for i < 64, `a` of lane 127 - i beyond
+        const int from = (63 - lane) * 4;
+        const uint64_t rb = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)(uint32_t)(b >> 32)) << 32) |
+                            (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)(uint32_t)b);
+        const uint64_t ra = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)(uint32_t)(a >> 32)) << 32) |
+                            (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)(uint32_t)a);
+        lo = min_u64(lo, rb);
+        hi = min_u64(hi, ra);
+        bitonic_merge128(lo, hi, lane);
+        if (lane >= k) lo = KEY_NONE;
+        if (lane + 64 >= k) hi = KEY_NONE;
+        tau = k <= 64 ? readlane_u64(lo, k - 1) : readlane_u64(hi, k - 65);
     }
     // Register lists only, list still empty: takes 128 arbitrary keys (two per lane, KEY_NONE =
     // none) at the cost of one sort instead of up to 128 inserts.

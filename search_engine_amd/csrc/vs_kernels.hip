@@ -958,6 +958,7 @@ struct HammingArgs {
     uint32_t row_vecs;
     uint32_t docid_base;
     uint32_t k;
+    uint32_t park = 0;  // non-zero: candidates are parked and merged in batches (WaveTopK::park)
 };
 
 // Dense stretches of 192-byte rows. A row is one and a half 128-byte lines, so the quad
@@ -1012,6 +1013,10 @@ struct HammingPairs {
             const uint32_t r = 2u * ((uint32_t)p * 8 + g) + (j & 1);
             const uint64_t key = make_key(j == 0 ? ca : cb, docid_base + slot0 + r);
             const bool live = j < 2 && ((word >> r) & 1);
+            if (top->parks()) {
+                top->park(live && key < top->tau, key);
+                continue;
+            }
             uint64_t m = __ballot(live && key < top->tau);
             while (m) {
                 const int src = __builtin_ctzll(m);
@@ -1036,6 +1041,8 @@ __global__ __launch_bounds__(WAVES * 64) void scan_hamming_kernel(HammingArgs a)
         reinterpret_cast<uint32_t*>(smem + (size_t)WAVES * k * 8) + (size_t)wib * QCAP;
     WaveTopK top;
     top.init(reinterpret_cast<uint64_t*>(smem) + (size_t)wib * k, k, lane);
+    if (a.park)  // (the launcher adds the buffers behind the queues)
+        top.park_in(reinterpret_cast<uint64_t*>(smem + (size_t)WAVES * k * 8 + (size_t)WAVES * QCAP * 4) + (size_t)wib * 128);
 
     // this lane's share of the query: vectors sub, sub + 4, ...
     u32x4 q[NI];
@@ -1077,6 +1084,10 @@ __global__ __launch_bounds__(WAVES * 64) void scan_hamming_kernel(HammingArgs a)
             cnt += dpp_u32<0x4E, 0xF>(cnt);  // quad_perm [2,3,0,1]
             const uint64_t key = make_key(cnt, a.docid_base + slot[u]);
             const bool live = valid[u] && sub == 0;
+            if (top.parks()) {
+                top.park(live && key < top.tau, key);
+                continue;
+            }
             uint64_t m = __ballot(live && key < top.tau);
             while (m) {
                 const int src = __builtin_ctzll(m);
@@ -1092,11 +1103,13 @@ __global__ __launch_bounds__(WAVES * 64) void scan_hamming_kernel(HammingArgs a)
             HammingPairs<NT> pairs{a.rows, a.docid_base, lane, &top};
             pairs.load_query(a.query);
             scan_masked_slots<16 * U>(a.present, a.cand, a.n_slots, w, W, lane, queue, score_rows, pairs);
+            top.merge_parked();
             finish_block(top, smem, k, wib, lane, a.partial);
             return;
         }
     }
     scan_masked_slots<16 * U>(a.present, a.cand, a.n_slots, w, W, lane, queue, score_rows);
+    top.merge_parked();
     finish_block(top, smem, k, wib, lane, a.partial);
 }
 
@@ -1568,8 +1581,10 @@ hipError_t launch_scan_hamming(const SlabView& s, const void* d_query, const uin
     a.row_vecs = s.row_vecs;
     a.docid_base = s.docid_base;
     a.k = k;
+    // top-100 under a filter: an insert at a time was 30 to 40 us of every launch (50 M x 1536 bit)
+    a.park = (k > 32 && k <= (uint32_t)WaveTopK::REG_K) ? 1u : 0u;
     const uint32_t blocks = scan_grid_blocks(s, t, cand != nullptr);
-    const size_t lds = (size_t)WAVES * k * 8 + (size_t)WAVES * QCAP * 4;
+    const size_t lds = (size_t)WAVES * k * 8 + (size_t)WAVES * QCAP * 4 + (a.park ? (size_t)WAVES * 128 * 8 : 0);
     const uint32_t ni = (s.row_vecs + 3) / 4;
     hipError_t e;
     if (ni <= 1) e = launch_hamming_t<1, 4>(a, blocks, lds, t, stream);
@@ -1777,6 +1792,8 @@ hipError_t launch_scan_hamming_multi(const SlabView& s, const void* d_queries, u
     m.query_stride = query_stride;
     m.n_q = n_q;
     m.partial_stride = (uint64_t)blocks * k;
+    // (four lists per wave leave no registers for batched insertion: tried, the kernel spilled and a dense
+    // pass took twice as long)
     const size_t lds = (size_t)HQ * WAVES * k * 8 + (size_t)WAVES * QCAP * 4;
     const dim3 grid(blocks), block(WAVES * 64);
     const uint32_t ni = (s.row_vecs + 3) / 4;
