@@ -172,3 +172,36 @@ def test_batch_device_entry_point_on_a_binary_store(gpu_ctx):
             assert (skeys.cpu().numpy().view(np.uint64) & 0xFFFFFFFF).tolist() == ids.tolist()
     finally:
         store.destroy()
+
+
+@pytest.mark.parametrize("k", [32, 33, 64, 65, 100, 128])
+@pytest.mark.parametrize("order", ["improving", "worsening", "ties", "random"])
+def test_top_k_lists_filled_in_batches(gpu_ctx, k, order):
+    """For 32 < k <= 128 a wave parks candidates and merges 65 or more of them into its list at once
+    (k = 32 inserts one at a time: the same answers). Adversarial arrival orders: every row better
+    than all before it (each one passes the bound, merge after merge), every row worse (nothing
+    passes once the list is full), long runs of equal distances (order by docid), and random; under
+    no filter, a dense one and one that leaves fewer candidates than k."""
+    n, dim = 64 * 400, 1536
+    rng = np.random.default_rng(k * 7 + len(order))
+    q = np.ones(dim, np.float32)
+    # a row's distance to the all-ones query = its number of non-positive entries
+    if order == "improving":
+        zeros = np.linspace(dim - 1, 0, n).astype(int)
+    elif order == "worsening":
+        zeros = np.linspace(0, dim - 1, n).astype(int)
+    elif order == "ties":
+        zeros = (np.arange(n) // 977 % 5) * 3 + 10
+    else:
+        zeros = rng.integers(0, dim, n)
+    vectors = np.ones((n, dim), np.float32)
+    cols = rng.permuted(np.tile(np.arange(dim), (n, 1)), axis=1)
+    vectors[np.arange(n)[:, None], cols] = np.where(np.arange(dim)[None, :] < zeros[:, None], -1.0, 1.0)
+    store = make_bin_store(gpu_ctx, vectors)
+    try:
+        few = np.zeros(n, bool)
+        few[rng.choice(n, k - 7, replace=False)] = True
+        for mask in (None, facet_mask(n, 60), facet_mask(n, 4), oracle.bool_to_mask(few)):
+            check(store, vectors, q, k, mask)
+    finally:
+        store.destroy()
