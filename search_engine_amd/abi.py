@@ -398,7 +398,9 @@ class Store:
         return b.value
 
     def search_batch_device(self, d_queries, n_q, dim, k, d_mask, d_workspace, d_out_keys, stream=0):
-        """Batched bf16 matrix-core scan; raw device addresses, asynchronous on `stream`."""
+        """vs_search_batch_device: up to 256 queries sharing passes over the rows (bf16 matrix cores,
+        8 / 32 f32 queries per pass, 4 binary ones; other stores one scan per query); keys out. Raw
+        device addresses, asynchronous on `stream`."""
         self._ck(lib.vs_search_batch_device(self.handle, d_queries, n_q, dim, k, d_mask, d_workspace,
                                             d_out_keys, stream))
 
