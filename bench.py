@@ -395,6 +395,17 @@ def main():
                     and t.get("pass_percent") == pass_percent and t.get("dim", dim) == dim)
             return t.get("hbm_bytes_per_launch") if same else None
 
+        def recorded_batch_traffic():
+            """The same for one batched bf16 call (every kernel of it), profiles/scan_traffic_bf16_batch256.json."""
+            tpath = os.path.join(ROOT, "profiles", f"scan_traffic_bf16_batch{n_q}.json")
+            if not os.path.exists(tpath):
+                return None
+            with open(tpath) as f:
+                t = json.load(f)
+            same = (t.get("docs") == args.docs and t.get("dim") == dim and t.get("n_gpus") == world
+                    and t.get("pass_percent") == args.pass_percent and t.get("batch_queries") == n_q)
+            return t.get("hbm_bytes_per_launch") if same else None
+
         what = {"f32": "cosine (arroy Angular)", "bf16": "cosine (arroy Angular)", "bin1": "Hamming"}[args.dtype]
         unit = "bit binary-quantised" if bin1 else f"dim {args.dtype}"
         line = {
@@ -435,7 +446,8 @@ def main():
                 flop = 2.0 * n_local * dim * 256
                 line["roofline"] = {
                     "bound": "hbm", "achieved": round(algo / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                    "traffic": recorded_batch_traffic(),
                     "kernel": "scan_batch_bf16_kernel (both passes, merges and the query prologue included)",
                     "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(ms, 4),
                     "mfma_tflops": round(flop / (ms * 1e-3) / 1e12, 1),
