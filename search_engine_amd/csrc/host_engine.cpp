@@ -826,7 +826,9 @@ void VectorSort::fill_buffer() {
     }
     if (!emitted_.is_empty()) {  // a refill: the documents handed out so far leave the candidates for good
         live_ -= emitted_;
+        candidates_ -= emitted_;
         emitted_ = DocSet();
+        emitted_from_live_ = 0;
     }
     std::vector<std::vector<std::pair<DocumentId, float>>> per_store;
     for (auto& reader : open_readers(ctx_, embedder_index_))
@@ -839,37 +841,48 @@ void VectorSort::preload(std::vector<std::vector<std::pair<DocumentId, float>>> 
 }
 
 void VectorSort::start_iteration(DocSet candidates) {
-    candidates_len_ = candidates.len();
-    live_ = vector_candidates_.intersect(candidates, &live_len_);
+    candidates_ = std::move(candidates);
+    live_ = vector_candidates_.intersect(candidates_, nullptr);
     emitted_ = DocSet();
+    emitted_from_live_ = 0;
+    finished_ = false;
     fill_buffer();
 }
 
 std::optional<RankingRuleOutput> VectorSort::next_bucket() {
+    // The reference looks at `candidates` and at `vector_candidates & candidates` before it looks
+    // at its cache (vector_sort.rs:96-109). If either is empty no cached document can still be
+    // live, so looking at the cache first gives the same answers -- and the two cardinalities, a
+    // pass over N / 64 words each for a universe nobody has counted yet, are only needed once the
+    // cache has run dry, which a request that is served from its first fill never sees.
     for (;;) {  // the reference recurses after a refill
-        if (candidates_len_ == 0) return std::nullopt;
-        if (live_len_ == 0) {
-            // Mirrors the reference's assignment order (vector_sort.rs:102-109): the
-            // candidates are cleared first, so the bucket that is returned is empty.
-            candidates_len_ = 0;
-            return RankingRuleOutput{ScoreDetails::vector(std::nullopt), DocSet()};
-        }
+        if (finished_) return std::nullopt;
         while (cursor_ < cached_sorted_docids_.size()) {
             const auto [docid, distance] = cached_sorted_docids_[cursor_++];
             if (live_.contains(docid) && !emitted_.contains(docid)) {
                 float score = 1.0f - distance;
                 if (distribution_shift_) score = distribution_shift_->shift(score);
                 emitted_.insert(docid);
-                --candidates_len_;
-                --live_len_;
+                ++emitted_from_live_;
                 return RankingRuleOutput{ScoreDetails::vector(score), DocSet::from_ids({docid})};
             }
+        }
+        // every emitted document was in live_, and live_ is a subset of the candidates
+        if (candidates_.len() == emitted_from_live_) {  // `candidates` is empty (:96-98)
+            finished_ = true;
+            return std::nullopt;
+        }
+        if (live_.len() == emitted_from_live_) {
+            // Mirrors the reference's assignment order (vector_sort.rs:102-109): the
+            // candidates are cleared first, so the bucket that is returned is empty.
+            finished_ = true;
+            return RankingRuleOutput{ScoreDetails::vector(std::nullopt), DocSet()};
         }
         // the cache is exhausted: refill it and run again
         fill_buffer();
         if (cached_sorted_docids_.empty()) {
             // no document with a vector is left in the universe
-            candidates_len_ = 0;
+            finished_ = true;
             return RankingRuleOutput{ScoreDetails::vector(std::nullopt), DocSet()};
         }
     }

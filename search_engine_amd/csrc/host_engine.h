@@ -264,11 +264,13 @@ class VectorSort : public RankingRule {
     DocSet vector_candidates_;
     // The reference keeps `candidates`, removes every emitted document from it and recomputes
     // vector_candidates & candidates in every next_bucket (vector_sort.rs:100,118). Only that
-    // intersection and the two cardinalities are ever looked at, so they are what is kept: live_ as
-    // of the last (re)fill -- untouched in between, so that it can share its words with the
-    // caller's universe and keep their device copy -- and the documents emitted since.
-    DocSet live_, emitted_;
-    uint64_t candidates_len_ = 0, live_len_ = 0;
+    // intersection and whether either set is used up are ever looked at, so what is kept is:
+    // candidates_ and live_ as of the last (re)fill -- untouched in between, so that they can share
+    // their words with the caller's universe and keep its device copy -- and the documents emitted
+    // since. The two cardinalities are counted when the cache runs dry, not before.
+    DocSet candidates_, live_, emitted_;
+    uint64_t emitted_from_live_ = 0;  // |emitted_|: how far live_ and candidates_ have been used up
+    bool finished_ = false;
     std::vector<std::pair<DocumentId, float>> cached_sorted_docids_;
     size_t cursor_ = 0;
     size_t limit_;
