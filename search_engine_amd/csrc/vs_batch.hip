@@ -4,7 +4,7 @@
 //
 // Shape of the work: scores = Docs[N x D] * Queries[256 x D]^T is a real dense
 // contraction (2*N*D*256 flop for N*D*2 bytes: 256 flop/byte), so it runs on the
-// matrix cores: v_mfma_f32_32x32x16_bf16, f32 accumulation. The N x 256 score
+// matrix cores: v_mfma_f32_32x32x16_bf16 (16x16x32 in the streaming pass), f32 accumulation. The N x 256 score
 // matrix is never written: every 256-document tile is reduced on the spot into
 // per-query top-k lists that live in LDS for the whole launch.
 //
@@ -589,7 +589,9 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
 // lines touched three steps ahead so that the LDS-DMA hits L2: 4.22 ms; rows through two alternating
 // register sets two steps ahead: 3.98 ms, although the loads alone then took 38 k instead of 45 k).
 // Rotated as below: 39 k cycles at 1.62 GHz, 3.64 ms -- the clock gives back part of what the cycles
-// gain (the chip is at its power limit with the matrix pipe 63 % busy).
+// gain (the chip is at its power limit with the matrix pipe 63 % busy). The same loop on
+// v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (same wave tile, same LDS bytes, same flop per cycle):
+// 40.8 k cycles at 1.75 GHz, 3.45 ms in a same-box A/B -- the chip holds a higher clock on that shape.
 constexpr int S_OFF_NORM = 2 * IMG_BYTES;             // f32[2][256], by tile parity
 constexpr int S_OFF_QUEUE = S_OFF_NORM + 2 * BM * 4;  // u64[2][QCAP]
 constexpr int S_OFF_QCOUNT = S_OFF_QUEUE + 2 * QCAP * 8;
@@ -624,6 +626,11 @@ __device__ __forceinline__ uint32_t lds_add_return(uint32_t* word, uint32_t v) {
     return old;
 }
 
+template <int V>
+struct Int {
+    static constexpr int value = V;
+};
+
 typedef const __attribute__((address_space(4))) uint32_t* const_u32;
 typedef const __attribute__((address_space(4))) uint64_t* const_u64;
 
@@ -633,22 +640,22 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63, wv = uniform_u32(tid >> 6);
     const uint32_t wm = wv >> 1, wn = wv & 1;
-    const uint32_t r32 = lane & 31, half = lane >> 5;
+    const uint32_t r16 = lane & 15, quarter = lane >> 4;
     float* snorm = reinterpret_cast<float*>(lds + S_OFF_NORM);
     uint64_t* queue = reinterpret_cast<uint64_t*>(lds + S_OFF_QUEUE);
     uint32_t* qcount = reinterpret_cast<uint32_t*>(lds + S_OFF_QCOUNT);
     const int k = (int)a.k;
     const uint32_t KS = a.ksteps;
 
-    // This lane's four query columns: the dot-product threshold a row's score must reach to beat
+    // This lane's eight query columns: the dot-product threshold a row's score must reach to beat
     // the query's bound (pq >= c2 * |row| is necessary for d < bound; the margin lets rounding only
     // admit too many). Constant for the launch.
-    float c2v[4];
-    bool col_ok[4];
+    float c2v[8];
+    bool col_ok[8];
     bool bad = false;
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const uint32_t q = wn * 128 + (uint32_t)n * 32 + r32;
+    for (int n = 0; n < 8; ++n) {
+        const uint32_t q = wn * 128 + (uint32_t)n * 16 + r16;
         col_ok[n] = q < a.n_q;
         c2v[n] = 3.0e38f;
         if (col_ok[n]) {
@@ -743,39 +750,51 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
     uint32_t image = 0;  // the image the step about to be multiplied lies in
     load_step(t0, 0, image);
 
-    const uint32_t frag_a = swz(wm * 64 + r32, half), frag_b = IMG_B + swz(wn * 128 + r32, half);
+    const uint32_t frag_a = swz(wm * 64 + r16, quarter), frag_b = IMG_B + swz(wn * 128 + r16, quarter);
     uint32_t t_prev = TILE_NONE;
 
-    // The loop is rotated by a quarter step: a step's one barrier stands before the matrix
-    // instructions of its LAST sub-step, whose fragments are in registers by then. Behind the barrier
+    // The matrix instruction is v_mfma_f32_16x16x32_bf16: a 64-element step is two sub-steps of 32, a
+    // wave's 64 x 128 tile 4 x 8 products of 16 x 16. Per flop it takes the cycles and the LDS bytes of
+    // the 32x32x16 form; the chip, which lowers its clock under this loop, holds a higher one with it.
+    // Lane l holds row l & 15, elements 8 * (l >> 4) .. + 8 of a sub-step: one 16-byte slot, and the
+    // image's swizzle is conflict-free for these reads as well.
+    //
+    // A step is walked in four phases of 16 matrix instructions: (sub-step, query half) = (0,0) (0,1)
+    // (1,0) (1,1). The loop is rotated by one phase: a step's one barrier stands before the matrix
+    // instructions of its LAST phase, whose fragments are in registers by then. Behind the barrier
     // a wave requests the first fragments of the NEXT step (its image is complete: that is what the
     // barrier says) and the rows of the step after that (into the image everybody has just finished
-    // reading), and then still has eight matrix instructions to issue while those reads fly. With the
+    // reading), and then still has sixteen matrix instructions to issue while those reads fly. With the
     // barrier between two steps instead, every step began with all eight waves waiting for LDS and
     // the matrix pipe idle: 49 k cycles per tile against 34 k without any barrier (loads left out).
-    bf16x8 fa[2][2], fb[2][4];
-    auto read_frags = [&](const unsigned char* img, int kk, bf16x8 (&xa)[2], bf16x8 (&xb)[4]) {
-        uint32_t fo_a = frag_a ^ ((uint32_t)kk << 5), fo_b = frag_b ^ ((uint32_t)kk << 5);
-        asm volatile("" : "+v"(fo_a), "+v"(fo_b));  // recompute per step, do not keep 8 addresses live
+    bf16x8 fa[2][4], fb[2][4];
+    auto read_a = [&](const unsigned char* img, int kk, bf16x8 (&xa)[4]) {
+        uint32_t fo = frag_a ^ ((uint32_t)kk << 6);
+        asm volatile("" : "+v"(fo));  // recompute per phase, do not keep the addresses live
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 4; ++m)
 #ifdef VS_ABL_NOLDSREAD
-            xa[m] = __builtin_bit_cast(bf16x8, u32x4{fo_a, 1u, 2u, 3u});
+            xa[m] = __builtin_bit_cast(bf16x8, u32x4{fo, 1u, 2u, 3u});
 #else
-            xa[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + m * 32 * 128 + fo_a));
+            xa[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + m * 16 * 128 + fo));
 #endif
+    };
+    auto read_b = [&](const unsigned char* img, int kk, int h, bf16x8 (&xb)[4]) {
+        uint32_t fo = frag_b ^ ((uint32_t)kk << 6);
+        asm volatile("" : "+v"(fo));
 #pragma unroll
         for (int n = 0; n < 4; ++n)
 #ifdef VS_ABL_NOLDSREAD
-            xb[n] = __builtin_bit_cast(bf16x8, u32x4{fo_b, 1u, 2u, 3u});
+            xb[n] = __builtin_bit_cast(bf16x8, u32x4{fo, 1u, 2u, 3u});
 #else
-            xb[n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + n * 32 * 128 + fo_b));
+            xb[n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + (h * 4 + n) * 16 * 128 + fo));
 #endif
     };
     // step 0 is complete and visible; its first fragments and the rows of step 1 are requested
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     __builtin_amdgcn_s_barrier();
-    read_frags(lds, 0, fa[0], fb[0]);
+    read_a(lds, 0, fa[0]);
+    read_b(lds, 0, 0, fb[0]);
     {
         const uint32_t t_1 = 1 < KS ? t0 : t1, k_1 = 1 < KS ? 1u : 0u;
 #pragma unroll
@@ -815,13 +834,13 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
         uint64_t w1[4];
         words_of(t1, w1);
 
-        f32x16 acc[2][4];
+        f32x4v acc[4][8];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
+            for (int n = 0; n < 8; ++n)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
+                for (int e = 0; e < 4; ++e) acc[m][n][e] = 0.0f;
 
         // the tile's own barrier: the previous tile's survivors are queued, this tile's norms have landed
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -851,41 +870,44 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
                     t_2 = t2;
                 }
             }
-            auto multiply = [&](const bf16x8 (&xa)[2], const bf16x8 (&xb)[4]) {
+            auto multiply = [&](auto H, const bf16x8 (&xa)[4], const bf16x8 (&xb)[4]) {
+                constexpr int h = decltype(H)::value;
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < 4; ++m)
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
 #ifdef VS_ABL_NOMFMA
                         asm volatile("" ::"v"(xa[m]), "v"(xb[n]));
 #else
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[m], xb[n], acc[m][n], 0, 0, 0);
+                        acc[m][h * 4 + n] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[m], xb[n], acc[m][h * 4 + n], 0, 0, 0);
 #endif
             };
-            // sub-steps 0 .. 2: the fragments of the next one first (the scheduler would sink them to
+            // phases 0 .. 2: the fragments of the next one first (the scheduler would sink them to
             // their first use), the next step's query pieces in between
-            // (this step's first fragments, requested eight matrix instructions ago: waiting for them here,
-            // before anything else is requested, keeps the compiler from waiting for everything later)
+            // (this step's first fragments, requested sixteen matrix instructions ago: waiting for them
+            // here, before anything else is requested, keeps the compiler from waiting for everything later)
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-            read_frags(img, 1, fa[1], fb[1]);
+            read_b(img, 0, 1, fb[1]);
             __builtin_amdgcn_sched_barrier(0);
 #ifndef VS_ABL_NOLOAD
             load_piece(t_1, k_1, other, 4);
             load_piece(t_1, k_1, other, 5);
 #endif
-            multiply(fa[0], fb[0]);
+            multiply(Int<0>{}, fa[0], fb[0]);
             __builtin_amdgcn_sched_barrier(0);
-            read_frags(img, 2, fa[0], fb[0]);
+            read_a(img, 1, fa[1]);
+            read_b(img, 1, 0, fb[0]);
             __builtin_amdgcn_sched_barrier(0);
 #ifndef VS_ABL_NOLOAD
             load_piece(t_1, k_1, other, 6);
             load_piece(t_1, k_1, other, 7);
 #endif
-            multiply(fa[1], fb[1]);
+            multiply(Int<1>{}, fa[0], fb[1]);
             __builtin_amdgcn_sched_barrier(0);
-            read_frags(img, 3, fa[1], fb[1]);
+            read_b(img, 1, 1, fb[1]);
             __builtin_amdgcn_sched_barrier(0);
-            multiply(fa[0], fb[0]);
+            multiply(Int<0>{}, fa[1], fb[0]);
             __builtin_amdgcn_sched_barrier(0);
             // my pieces of the next step are in LDS, my reads of this one are done ...
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
@@ -894,67 +916,67 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
 #ifndef VS_ABL_NOBARRIER
             __builtin_amdgcn_s_barrier();
 #endif
-            read_frags(lds + other * IMG_BYTES, 0, fa[0], fb[0]);
+            read_a(lds + other * IMG_BYTES, 0, fa[0]);
+            read_b(lds + other * IMG_BYTES, 0, 0, fb[0]);
             __builtin_amdgcn_sched_barrier(0);
 #ifndef VS_ABL_NOLOAD
 #pragma unroll
             for (int pc = 0; pc < 4; ++pc) load_piece(t_2, k_2, image, pc);
 #endif
-            multiply(fa[1], fb[1]);
+            multiply(Int<1>{}, fa[1], fb[1]);
             __builtin_amdgcn_sched_barrier(0);
             image = other;
         }
 
         // ---- register test: t = score - |row| * c2[query]; per query column the largest t.
-        // accumulator element e of MFMA tile (m, n) is row m*32 + (e&3) + 8*(e>>2) + 4*half,
-        // column n*32 + r32 of the wave tile
+        // accumulator element e of product (m, n) is row m*16 + 4*quarter + e, column n*16 + r16
+        // of the wave tile
         {
-            const float* norm_mine = snorm + par * BM + wm * 64 + 4 * half;
-            float tmax[2][4];
+            const float* norm_mine = snorm + par * BM + wm * 64 + 4 * quarter;
+            f32x4v pn4[4];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) tmax[0][n] = tmax[1][n] = -__builtin_inff();
+            for (int m = 0; m < 4; ++m) pn4[m] = *reinterpret_cast<const f32x4v*>(norm_mine + m * 16);
+            float tmax[8];
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int n = 0; n < 8; ++n) {
+                tmax[n] = -__builtin_inff();
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4v pn4 = *reinterpret_cast<const f32x4v*>(norm_mine + m * 32 + 8 * g);
+                for (int m = 0; m < 4; ++m)
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
+                    for (int e = 0; e < 4; ++e)
+                        tmax[n] = __builtin_fmaxf(tmax[n], __builtin_fmaf(-pn4[m][e], c2v[n], acc[m][n][e]));
+            }
 #pragma unroll
-                        for (int n = 0; n < 4; ++n)
-                            tmax[m][n] = __builtin_fmaxf(tmax[m][n], __builtin_fmaf(-pn4[jj], c2v[n], acc[m][n][g * 4 + jj]));
-                }
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int n = 0; n < 4; ++n) {
+            for (int n = 0; n < 8; ++n) {
 #ifdef VS_ABL_NOHITS
-                    const bool lane_hit = false && tmax[m][n] >= 0.0f;
+                const bool lane_hit = tmax[n] >= 3.0e38f;
 #else
-                    const bool lane_hit = tmax[m][n] >= 0.0f && col_ok[n];
+                const bool lane_hit = tmax[n] >= 0.0f && col_ok[n];
 #endif
-                    if (__ballot(lane_hit) == 0) continue;  // wave-uniform, the common case
-                    uint32_t hit = 0;
-                    if (lane_hit) {
+                if (__ballot(lane_hit) == 0) continue;  // wave-uniform, the common case
+                uint32_t hit = 0;
+                if (lane_hit) {
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const float t = __builtin_fmaf(-norm_mine[m * 32 + (e & 3) + 8 * (e >> 2)], c2v[n], acc[m][n][e]);
-                            hit |= (t >= 0.0f) ? (1u << e) : 0u;
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float t = __builtin_fmaf(-pn4[m][e], c2v[n], acc[m][n][e]);
+                            hit |= (t >= 0.0f) ? (1u << (m * 4 + e)) : 0u;
                         }
-                    }
-                    while (hit) {
-                        const uint32_t e = (uint32_t)__builtin_ctz(hit);
-                        hit &= hit - 1;
-                        float v = acc[m][n][0];
-#pragma unroll
-                        for (int jj = 1; jj < 16; ++jj) v = (e == (uint32_t)jj) ? acc[m][n][jj] : v;
-                        const uint32_t wrow = (uint32_t)m * 32 + (e & 3) + 8u * (e >> 2) + 4u * half;
-                        const uint32_t idx = lds_add_return(qcount + par, 1u);
-                        if (idx < (uint32_t)QCAP)
-                            queue[par * QCAP + idx] = ((uint64_t)__float_as_uint(v) << 32) |
-                                                      ((wn * 128 + (uint32_t)n * 32 + r32) << 8) | (wm * 64 + wrow);
-                    }
                 }
+                while (hit) {
+                    const uint32_t e = (uint32_t)__builtin_ctz(hit);
+                    hit &= hit - 1;
+                    float v = acc[0][n][0];
+#pragma unroll
+                    for (int jj = 1; jj < 16; ++jj) v = (e == (uint32_t)jj) ? acc[jj >> 2][n][jj & 3] : v;
+                    const uint32_t wrow = (e >> 2) * 16u + 4u * quarter + (e & 3u);
+                    const uint32_t idx = lds_add_return(qcount + par, 1u);
+                    if (idx < (uint32_t)QCAP)
+                        queue[par * QCAP + idx] = ((uint64_t)__float_as_uint(v) << 32) |
+                                                  ((wn * 128 + (uint32_t)n * 16 + r16) << 8) | (wm * 64 + wrow);
+                }
+            }
         }
         t_prev = t0;
         t0 = t1;
