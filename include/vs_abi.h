@@ -252,7 +252,11 @@ int32_t vs_search_mask(vs_store* s, const float* query, uint32_t dim, uint32_t k
  * bf16 up to 1536 dimensions) share each pass over the rows when k <= 128, and
  * every query's result is bit-identical to its own vs_search; on binary stores
  * (rows of up to 2048 bits, k <= 128) four queries share a pass, results equal
- * to vs_search's; anything else is one scan per query. No reference counterpart (the reference searches one vector per
+ * to vs_search's; anything else is one scan per query. On the matrix-core path a
+ * filter that keeps at most a quarter of the items has its candidates copied
+ * into a dense slab first (inside the call's own workspace: up to a quarter of
+ * the store's bytes), so that only they are read and multiplied; the result is
+ * the same. No reference counterpart (the reference searches one vector per
  * request). */
 int32_t vs_search_batch(vs_store* s, const float* queries, uint32_t n_q, uint32_t dim,
                         uint32_t k, const uint64_t* mask_words, uint64_t n_mask_words,

@@ -1318,4 +1318,227 @@ hipError_t launch_scan_batch_bf16(const SlabView& s, const float* d_queries, uin
                               out_keys, out_ids, out_dist, out_n, stream, a.gate);
 }
 
+
+// ---- selective filters: the candidates gathered into a dense slab ----------------------------
+//
+// The matrix-core scan multiplies whole 256-row tiles, so under a filter that keeps one row in ten
+// it would still read and multiply all of them. Below a quarter of the rows the candidates are
+// copied once into a dense slab of their own (rows, norms, an all-ones present bitmap), in slot
+// order, the two passes above run on that slab, and the compact row numbers in their result are
+// turned back into docids. Slot order is kept, so ties still break by docid. Cost: the candidate
+// bytes are read twice and written once instead of every row being read once.
+
+namespace {
+
+constexpr uint32_t GATHER_BLOCK_WORDS = 1024;  // mask words per workgroup of the counting kernels: 256 threads x 4
+
+__device__ __forceinline__ uint64_t candidate_word(const uint64_t* present, const uint64_t* cand, uint64_t i,
+                                                   uint64_t n_words) {
+    return i < n_words ? present[i] & cand[i] : 0ull;
+}
+
+// exclusive prefix sum over the 256 threads of a workgroup; *total = the sum
+__device__ __forceinline__ uint32_t block_exclusive_256(uint32_t v, uint32_t* wave_sums, uint32_t* total) {
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= (uint32_t)d) inc += o;
+    }
+    if (lane == 63) wave_sums[wv] = inc;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {
+        const uint32_t x = wave_sums[i];
+        if (i < wv) before += x;
+        all += x;
+    }
+    __syncthreads();
+    *total = all;
+    return before + inc - v;
+}
+
+}  // namespace
+
+// candidates per block of 1024 mask words
+__global__ __launch_bounds__(256) void gather_count_kernel(const uint64_t* present, const uint64_t* cand,
+                                                           uint64_t n_words, uint32_t* block_sums) {
+    __shared__ uint32_t wave_sums[4];
+    const uint64_t w0 = (uint64_t)blockIdx.x * GATHER_BLOCK_WORDS + (uint64_t)threadIdx.x * 4;
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c += (uint32_t)__builtin_popcountll(candidate_word(present, cand, w0 + j, n_words));
+    uint32_t total;
+    (void)block_exclusive_256(c, wave_sums, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// block_sums -> exclusive offsets in place; head[0] = min(number of candidates, cap). One workgroup.
+__global__ __launch_bounds__(256) void gather_scan_kernel(uint32_t* block_sums, uint32_t n_blocks, uint32_t cap,
+                                                          uint32_t* head) {
+    __shared__ uint32_t wave_sums[4];
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += 256) {
+        const uint32_t i = b0 + threadIdx.x;
+        const uint32_t v = i < n_blocks ? block_sums[i] : 0;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_256(v, wave_sums, &total);
+        if (i < n_blocks) block_sums[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) head[0] = carry < cap ? carry : cap;
+}
+
+// map[i] = slot of the i-th candidate, in slot order
+__global__ __launch_bounds__(256) void gather_map_kernel(const uint64_t* present, const uint64_t* cand,
+                                                         uint64_t n_words, const uint32_t* block_offsets,
+                                                         uint32_t cap, uint32_t* map) {
+    __shared__ uint32_t wave_sums[4];
+    const uint64_t w0 = (uint64_t)blockIdx.x * GATHER_BLOCK_WORDS + (uint64_t)threadIdx.x * 4;
+    uint64_t w[4];
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        w[j] = candidate_word(present, cand, w0 + j, n_words);
+        c += (uint32_t)__builtin_popcountll(w[j]);
+    }
+    uint32_t total;
+    uint32_t at = block_offsets[blockIdx.x] + block_exclusive_256(c, wave_sums, &total);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint64_t x = w[j];
+        while (x) {
+            const uint32_t bit = (uint32_t)__builtin_ctzll(x);
+            x &= x - 1;
+            if (at < cap) map[at] = (uint32_t)((w0 + j) * 64 + bit);
+            ++at;
+        }
+    }
+}
+
+// rows, norms and the present words of the dense slab; one thread per 16-byte vector
+__global__ __launch_bounds__(256) void gather_rows_kernel(const u32x4* rows, const float* norms, uint32_t row_vecs,
+                                                          const uint32_t* map, const uint32_t* head, u32x4* rows_c,
+                                                          float* norms_c, uint64_t* present_c) {
+    const uint32_t n = head[0];
+    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i = (uint32_t)(g / row_vecs), v = (uint32_t)(g - (uint64_t)i * row_vecs);
+    if (i >= n) return;
+    const uint32_t slot = map[i];
+    rows_c[g] = __builtin_nontemporal_load(rows + (uint64_t)slot * row_vecs + v);
+    if (v == 0) {
+        norms_c[i] = norms[slot];
+        if ((i & 63u) == 0) present_c[i >> 6] = n - i >= 64 ? ~0ull : (1ull << (n - i)) - 1ull;
+    }
+}
+
+// compact row numbers in the result back to docids
+__global__ __launch_bounds__(256) void gather_translate_kernel(const uint32_t* map, uint32_t docid_base, uint32_t total,
+                                                               uint64_t* keys, uint32_t* ids, const uint32_t* counts,
+                                                               uint32_t k) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    if (keys) {
+        const uint64_t key = keys[i];
+        if (key != KEY_NONE) keys[i] = (key & 0xFFFFFFFF00000000ull) | (uint64_t)(docid_base + map[(uint32_t)key]);
+    }
+    if (ids && i % k < counts[i / k]) ids[i] = docid_base + map[ids[i]];
+}
+
+namespace {
+
+struct GatherPlan {
+    uint64_t cap;  // rows of the dense slab: the candidate count rounded up to whole tiles
+    uint32_t n_blocks;
+    size_t off_head, off_map, off_present, off_norms, off_rows, off_inner, total;
+};
+
+GatherPlan plan_gather(const SlabView& s, uint64_t max_candidates, uint32_t k) {
+    GatherPlan g;
+    g.cap = (max_candidates + BM - 1) / BM * BM;
+    if (g.cap == 0) g.cap = BM;
+    g.n_blocks = (uint32_t)(((s.n_slots >> 6) + GATHER_BLOCK_WORDS - 1) / GATHER_BLOCK_WORDS);
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    size_t off = up((size_t)g.n_blocks * 4);  // block sums / offsets at +0
+    g.off_head = off;
+    off += 256;
+    g.off_map = off;
+    off += up((size_t)g.cap * 4);
+    g.off_present = off;
+    off += up((size_t)g.cap / 8 + 64);
+    g.off_norms = off;
+    off += up((size_t)g.cap * 4);
+    g.off_rows = off;
+    off += up((size_t)g.cap * s.row_vecs * 16);
+    g.off_inner = off;
+    SlabView c = s;
+    c.n_slots = g.cap;
+    g.total = off + (size_t)plan_batch(c, k).total;
+    return g;
+}
+
+}  // namespace
+
+uint64_t batch_gather_workspace_bytes(const SlabView& s, uint64_t max_candidates, uint32_t k) {
+    return plan_gather(s, max_candidates, k).total;
+}
+
+hipError_t launch_count_candidates(const SlabView& s, const uint64_t* cand, uint32_t* d_block_sums,
+                                   uint32_t* d_count, hipStream_t stream) {
+    const uint32_t n_blocks = (uint32_t)(((s.n_slots >> 6) + GATHER_BLOCK_WORDS - 1) / GATHER_BLOCK_WORDS);
+    hipLaunchKernelGGL(gather_count_kernel, dim3(n_blocks), dim3(256), 0, stream, s.present, cand, s.n_slots >> 6,
+                       d_block_sums);
+    hipLaunchKernelGGL(gather_scan_kernel, dim3(1), dim3(256), 0, stream, d_block_sums, n_blocks, 0xFFFFFFFFu, d_count);
+    return hipGetLastError();
+}
+
+uint64_t count_candidates_workspace_bytes(const SlabView& s) {
+    return (((s.n_slots >> 6) + GATHER_BLOCK_WORDS - 1) / GATHER_BLOCK_WORDS) * 4 + 256;
+}
+
+hipError_t launch_scan_batch_bf16_gathered(const SlabView& s, const float* d_queries, uint32_t n_q,
+                                           const uint64_t* cand, uint64_t max_candidates, uint32_t k,
+                                           void* workspace, uint64_t* out_keys, uint32_t* out_ids, float* out_dist,
+                                           uint32_t* out_n, hipStream_t stream) {
+    if (!cand || max_candidates == 0 || max_candidates > 0xFFFFFF00ull || (s.n_slots & 63) != 0 || s.n_slots == 0 ||
+        (!out_keys && !(out_ids && out_n)))
+        return hipErrorInvalidValue;
+    const GatherPlan g = plan_gather(s, max_candidates, k);
+    unsigned char* ws = static_cast<unsigned char*>(workspace);
+    uint32_t* block_sums = reinterpret_cast<uint32_t*>(ws);
+    uint32_t* head = reinterpret_cast<uint32_t*>(ws + g.off_head);
+    uint32_t* map = reinterpret_cast<uint32_t*>(ws + g.off_map);
+    uint64_t* present_c = reinterpret_cast<uint64_t*>(ws + g.off_present);
+    float* norms_c = reinterpret_cast<float*>(ws + g.off_norms);
+    u32x4* rows_c = reinterpret_cast<u32x4*>(ws + g.off_rows);
+    const uint64_t n_words = s.n_slots >> 6;
+    // rows past the candidates are not present; their norms and the map entries the translation may
+    // never reach still have to be defined
+    hipError_t e = hipMemsetAsync(ws + g.off_map, 0, g.off_rows - g.off_map, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(gather_count_kernel, dim3(g.n_blocks), dim3(256), 0, stream, s.present, cand, n_words, block_sums);
+    hipLaunchKernelGGL(gather_scan_kernel, dim3(1), dim3(256), 0, stream, block_sums, g.n_blocks, (uint32_t)g.cap, head);
+    hipLaunchKernelGGL(gather_map_kernel, dim3(g.n_blocks), dim3(256), 0, stream, s.present, cand, n_words, block_sums,
+                       (uint32_t)g.cap, map);
+    const uint64_t vecs = g.cap * s.row_vecs;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)((vecs + 255) / 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const u32x4*>(s.rows), s.norms, s.row_vecs, map, head, rows_c, norms_c, present_c);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    SlabView c = s;
+    c.rows = rows_c;
+    c.norms = norms_c;
+    c.present = present_c;
+    c.n_slots = g.cap;
+    c.docid_base = 0;
+    e = launch_scan_batch_bf16(c, d_queries, n_q, nullptr, k, ws + g.off_inner, out_keys, out_ids, out_dist, out_n, stream);
+    if (e != hipSuccess) return e;
+    const uint32_t total = n_q * k;
+    hipLaunchKernelGGL(gather_translate_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, map, s.docid_base, total,
+                       out_keys, out_ids, out_n, k);
+    return hipGetLastError();
+}
+
 }  // namespace vs

@@ -103,6 +103,19 @@ hipError_t launch_scan_batch_bf16(const SlabView& s, const float* d_queries, uin
                                   const uint64_t* cand, uint32_t k, void* workspace,
                                   uint64_t* out_keys, uint32_t* out_ids, float* out_dist,
                                   uint32_t* out_n, hipStream_t stream);
+// The same search under a selective filter: the candidates (present & cand, at most `max_candidates`
+// of them: any upper bound; rows beyond it would be dropped) are first gathered into a dense slab inside
+// `workspace` (batch_gather_workspace_bytes), in slot order, so that the scan reads and multiplies only
+// them. Same outputs; docids are those of the store.
+uint64_t batch_gather_workspace_bytes(const SlabView& s, uint64_t max_candidates, uint32_t k);
+hipError_t launch_scan_batch_bf16_gathered(const SlabView& s, const float* d_queries, uint32_t n_q,
+                                           const uint64_t* cand, uint64_t max_candidates, uint32_t k,
+                                           void* workspace, uint64_t* out_keys, uint32_t* out_ids, float* out_dist,
+                                           uint32_t* out_n, hipStream_t stream);
+// *d_count = number of candidates (present & cand); d_block_sums: count_candidates_workspace_bytes bytes.
+uint64_t count_candidates_workspace_bytes(const SlabView& s);
+hipError_t launch_count_candidates(const SlabView& s, const uint64_t* cand, uint32_t* d_block_sums,
+                                   uint32_t* d_count, hipStream_t stream);
 
 // ‖row‖₂ for slots [slot0, slot0 + n) of an angular slab, same summation order
 // as the scan uses for ⟨row, query⟩.

@@ -314,7 +314,25 @@ int32_t run_batch_and_fetch(vs_store* s, const vs::SlabView& v, Workspace* ws, c
     const size_t chunk_q = VS_BATCH_MAX_QUERIES;
     const size_t q_bytes = chunk_q * s->dim * 4;
     const size_t res_bytes = chunk_q * k * 8 + chunk_q * 4;  // ids, distances, counts
-    const size_t ws_bytes = (size_t)vs::batch_workspace_bytes(v, k);
+    // Under a filter that keeps at most a quarter of the rows the candidates are gathered into a
+    // dense slab first (the matrix-core scan works on whole 256-row tiles; gathered, it reads the
+    // candidate bytes three times instead of every row once). Their number decides, so it is
+    // counted on the device: one small launch and one wait per call.
+    uint64_t n_cand = 0;
+    static const bool gather_allowed = getenv("VS_BATCH_NO_GATHER") == nullptr;  // measurement switch
+    if (d_cand && gather_allowed) {
+        if (int32_t rc = grow(&ws->d_partial, &ws->partial_bytes, (size_t)vs::count_candidates_workspace_bytes(v)))
+            return rc;
+        HIP_TRY(vs::launch_count_candidates(v, d_cand, reinterpret_cast<uint32_t*>(ws->d_partial), ws->d_n, ws->stream));
+        HIP_TRY(hipMemcpyAsync(ws->h_pinned, ws->d_n, 4, hipMemcpyDeviceToHost, ws->stream));
+        HIP_TRY(hipStreamSynchronize(ws->stream));
+        uint32_t c;
+        memcpy(&c, ws->h_pinned, 4);
+        n_cand = c;
+    }
+    const bool gather = n_cand > 0 && n_cand * 4 <= v.n_slots;
+    const size_t ws_bytes = gather ? (size_t)vs::batch_gather_workspace_bytes(v, n_cand, k)
+                                   : (size_t)vs::batch_workspace_bytes(v, k);
     // one device block: queries | kernel workspace | results
     const size_t off_ws = (q_bytes + 255) / 256 * 256, off_res = off_ws + (ws_bytes + 255) / 256 * 256;
     if (int32_t rc = grow(&ws->d_batch, &ws->batch_bytes, off_res + res_bytes)) return rc;
@@ -327,8 +345,12 @@ int32_t run_batch_and_fetch(vs_store* s, const vs::SlabView& v, Workspace* ws, c
         uint32_t* d_n = reinterpret_cast<uint32_t*>(ws->d_batch + off_res + chunk_q * k * 8);
         HIP_TRY(hipMemcpyAsync(d_q, h_queries + (size_t)at * s->dim, (size_t)m * s->dim * 4,
                                hipMemcpyHostToDevice, ws->stream));
-        HIP_TRY(vs::launch_scan_batch_bf16(v, d_q, m, d_cand, k, ws->d_batch + off_ws, nullptr, d_ids,
-                                           d_dist, d_n, ws->stream));
+        if (gather)
+            HIP_TRY(vs::launch_scan_batch_bf16_gathered(v, d_q, m, d_cand, n_cand, k, ws->d_batch + off_ws, nullptr,
+                                                        d_ids, d_dist, d_n, ws->stream));
+        else
+            HIP_TRY(vs::launch_scan_batch_bf16(v, d_q, m, d_cand, k, ws->d_batch + off_ws, nullptr, d_ids,
+                                               d_dist, d_n, ws->stream));
         HIP_TRY(hipMemcpyAsync(host.data(), ws->d_batch + off_res, res_bytes, hipMemcpyDeviceToHost,
                                ws->stream));
         HIP_TRY(hipStreamSynchronize(ws->stream));

@@ -143,6 +143,55 @@ def test_batch_parity_beyond_the_sample_pass(gpu_ctx, pass_percent, k, awkward):
         store.destroy()
 
 
+def test_batch_under_a_selective_filter_gathers_the_candidates(gpu_ctx):
+    """At most a quarter of the rows pass: vs_search_batch copies the candidates into a dense slab
+    (slot order kept) and scans that. 20 % of 393 k rows are more than the 256 sample tiles, so the
+    gathered slab goes through both passes; the planted near-duplicates outside the filter must not
+    come back, the identical rows inside it tie by docid."""
+    n, dim, base = 256 * 256 * 6 + 64, 64, 64 * 3
+    vectors = synthetic_vectors(n, dim, 0x6A7)
+    queries = synthetic_vectors(23, dim, 0x6A8)
+    rng = np.random.default_rng(77)
+    keep = rng.random(n) < 0.2
+    for j in range(queries.shape[0]):
+        for pos in rng.choice(n, 8, replace=False):
+            vectors[pos] = queries[j] + 0.05 * rng.standard_normal(dim).astype(np.float32)
+    vectors[5000:5030] = vectors[4999]
+    keep[4999:5030] = True
+    queries[2] = vectors[4999] * 3
+    vectors[9000] = 0.0
+    keep[9000] = True
+    docids = np.arange(n, dtype=np.uint32) + base
+    mask = oracle.bool_to_mask(np.concatenate([np.zeros(base, bool), keep]))
+    store = make_bf16_store(gpu_ctx, vectors, docids, docid_base=base)
+    try:
+        assert keep.sum() * 4 <= n and keep.sum() > 256 * 256
+        check_batch(store, vectors, queries, 10, mask, docids)
+    finally:
+        store.destroy()
+
+
+def test_batch_under_a_filter_of_a_few_rows(gpu_ctx):
+    """Three candidates (fewer than k, fewer than a tile), then candidates that are not items."""
+    n, dim = 5000, 32
+    rng = np.random.default_rng(3)
+    docids = np.sort(rng.choice(9000, n, replace=False)).astype(np.uint32)
+    vectors = synthetic_vectors(n, dim, 31)
+    queries = synthetic_vectors(5, dim, 32)
+    store = make_bf16_store(gpu_ctx, vectors, docids)
+    try:
+        few = np.zeros(9000, bool)
+        few[docids[[17, 2500, 4999]]] = True
+        results = store.search_batch(queries, 10, oracle.bool_to_mask(few))
+        assert all(sorted(ids.tolist()) == sorted(docids[[17, 2500, 4999]].tolist()) for ids, _ in results)
+        check_batch(store, vectors, queries, 10, oracle.bool_to_mask(few), docids)
+        absent = np.ones(9000, bool)
+        absent[docids] = False
+        assert all(ids.size == 0 for ids, _ in store.search_batch(queries, 10, oracle.bool_to_mask(absent)))
+    finally:
+        store.destroy()
+
+
 def test_batch_matches_single_query_ids(gpu_ctx):
     """Same store, same (already bf16-exact) queries: the batched and the single-query path
     agree on ids wherever distances are not within tolerance of each other."""

@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--queries", type=int, default=256)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--pass-percents", default="100,10")
+    ap.add_argument("--host-api", action="store_true",
+                    help="time vs_search_batch (host queries, host mask, host results) with the wall clock instead")
     args = ap.parse_args()
     from search_engine_amd import abi
     dev = torch.device("cuda", 0)
@@ -45,6 +47,20 @@ def main():
     keys = torch.empty(args.queries * args.k, dtype=torch.int64, device=dev)
     for p in [int(x) for x in args.pass_percents.split(",")]:
         mask = device_mask(0, n, p, dev)
+        if args.host_api:
+            import time
+            hq = q.cpu().numpy()
+            hm = None if p >= 100 else mask.cpu().numpy().view(np.uint64)
+            times = []
+            for r in range(args.reps + 1):
+                t0 = time.perf_counter()
+                store.search_batch(hq, args.k, hm)
+                if r:
+                    times.append((time.perf_counter() - t0) * 1e3)
+            t = float(np.median(times))
+            print(f"p={p:3d}%  {t:8.3f} ms/batch through vs_search_batch (uploads and downloads included)  "
+                  f"{args.queries / t * 1e3:10.0f} queries/s", flush=True)
+            continue
         times = []
         for r in range(args.reps + 1):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
