@@ -595,7 +595,9 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_bf16_kernel(BatchArgs a) 
 constexpr int S_OFF_NORM = 2 * IMG_BYTES;             // f32[2][256], by tile parity
 constexpr int S_OFF_QUEUE = S_OFF_NORM + 2 * BM * 4;  // u64[2][QCAP]
 constexpr int S_OFF_QCOUNT = S_OFF_QUEUE + 2 * QCAP * 8;
-constexpr int S_LDS = S_OFF_QCOUNT + 16;
+constexpr int S_OFF_MAP = S_OFF_QCOUNT + 16;  // u32[2][BM]: slots of the tile's rows (gathered form only)
+constexpr int S_LDS = S_OFF_MAP + 2 * BM * 4;
+constexpr uint32_t GATHER_SPAN = 0x40000000u;  // bytes a gathered tile's rows may lie apart
 static_assert(S_LDS <= 160 * 1024, "LDS carve exceeds 160 KiB");
 constexpr uint32_t TILE_NONE = 0xFFFFFFFFu;
 
@@ -614,6 +616,12 @@ struct StreamArgs {
     uint32_t* overflow;
     uint64_t n_slots;
     uint32_t row_vecs, ksteps, docid_base, k, n_q, cap;
+    // GATHER build only: the candidates' slots in slot order (padded to whole tiles with a valid
+    // slot), and head[0] = their number. `norms` is then indexed like `map`, `tiles` holds pairs
+    // (tile of the candidate list, slot of its first row), and the survivors' docid field is the
+    // position in the candidate list.
+    const uint32_t* map;
+    const uint32_t* head;
 };
 
 // atomicAdd on an LDS word, written out: before the builtin's ds_add the compiler waits for every
@@ -634,6 +642,7 @@ struct Int {
 typedef const __attribute__((address_space(4))) uint32_t* const_u32;
 typedef const __attribute__((address_space(4))) uint64_t* const_u64;
 
+template <bool GATHER>
 __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -679,16 +688,27 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
     const uint32_t G = gridDim.x, b = blockIdx.x;
     const uint32_t n_mine = count > b ? (count - b + G - 1) / G : 0;
     if (n_mine == 0) return;
-    auto tile_at = [&](uint32_t j) -> uint32_t { return j < n_mine ? tiles[b + j * G] : TILE_NONE; };
+    // rows the tiles index: the store's slots, or the candidate list
+    const uint64_t n_rows = GATHER ? (uint64_t) * (const_u32)(uintptr_t)a.head : a.n_slots;
+    auto tile_at = [&](uint32_t j) -> uint32_t {
+        return j < n_mine ? tiles[(GATHER ? 2u : 1u) * (b + j * G)] : TILE_NONE;
+    };
+    // GATHER: the slot of the tile's first row (the base address of its loads)
+    auto slot_at = [&](uint32_t j) -> uint32_t { return GATHER && j < n_mine ? tiles[2u * (b + j * G) + 1u] : 0u; };
     const uint64_t n_words = a.n_slots >> 6;
     auto words_of = [&](uint32_t t, uint64_t (&w)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const uint64_t wi = 4 * (uint64_t)t + (uint64_t)i;
             uint64_t x = 0;
-            if (t != TILE_NONE && wi < n_words) {
-                x = present[wi];
-                if (a.cand) x &= cand[wi];
+            if constexpr (GATHER) {  // every row of the list is a candidate
+                const uint64_t first = (uint64_t)t * BM + 64u * (uint32_t)i;
+                if (t != TILE_NONE && first < n_rows) x = n_rows - first >= 64 ? ~0ull : (1ull << (n_rows - first)) - 1ull;
+            } else {
+                const uint64_t wi = 4 * (uint64_t)t + (uint64_t)i;
+                if (t != TILE_NONE && wi < n_words) {
+                    x = present[wi];
+                    if (a.cand) x &= cand[wi];
+                }
             }
             w[i] = x;
         }
@@ -698,43 +718,64 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
     const uint32_t row_bytes = a.row_vecs * 16u;
     const __amdgpu_buffer_rsrc_t qres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<u32x4*>(a.qrows), 0, (int)((uint32_t)BN * KS * 128u), 0x00020000);
-    auto doc_rsrc = [&](uint32_t t) {
+    // GATHER: the tile's rows lie anywhere above its first one, less than GATHER_SPAN bytes away
+    // (the launcher's tile list guarantees it); offsets with bit 30 set read zeros as before
+    auto doc_rsrc = [&](uint32_t t, uint32_t slot0) {
         const bool live = t != TILE_NONE;
-        return __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<u32x4*>(a.rows + (live ? (uint64_t)t * BM * a.row_vecs : 0)), 0,
-            live ? (int)((uint32_t)BM * row_bytes) : 0, 0x00020000);
+        if constexpr (GATHER)
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(a.rows + (live ? (uint64_t)slot0 * a.row_vecs : 0)),
+                                                     0, live ? (int)GATHER_SPAN : 0, 0x00020000);
+        else
+            return __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<u32x4*>(a.rows + (live ? (uint64_t)t * BM * a.row_vecs : 0)), 0,
+                live ? (int)((uint32_t)BM * row_bytes) : 0, 0x00020000);
     };
     const uint32_t dslot[2] = {(lane & 7) ^ (lane >> 4), (lane & 7) ^ (4 + (lane >> 4))};
     const uint32_t dva[2] = {(lane >> 3) * row_bytes + dslot[0] * 16u, (lane >> 3) * row_bytes + dslot[1] * 16u};
+    // GATHER: byte offset of this lane's row in piece i (row (wv * 4 + i) * 8 + (lane >> 3) of the
+    // tile) above the tile's first row, plus its slot. One tile's worth: the loads of a tile's
+    // first two steps go out during the last two steps of the tile before, and that is where the
+    // offsets are replaced.
+    uint32_t gva[4] = {0, 0, 0, 0};
+    uint32_t* smap = reinterpret_cast<uint32_t*>(lds + S_OFF_MAP);
+    auto offsets_from = [&](const uint32_t* m, uint32_t slot0) {  // m: the tile's 256 slots
+        const uint32_t r = wv * 32 + (opaque(lane) >> 3);  // (taken afresh: not worth a register across the K loop)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gva[i] = (m[r + 8 * (uint32_t)i] - slot0) * row_bytes + dslot[i & 1] * 16u;
+    };
     const uint32_t dvb[2] = {(lane >> 3) * (KS * 128u) + dslot[0] * 16u, (lane >> 3) * (KS * 128u) + dslot[1] * 16u};
     // A wave's eight pieces of a step go out one by one, spread over the step (documents first, they
     // have furthest to come; then queries): 64 pieces issued by all waves at
     // once queue up behind the CU's one load path (16 cycles a piece), and the waves stand in that
     // queue with the matrix pipe idle.
-    auto load_piece = [&](uint32_t t, uint32_t ks, uint32_t image, int pc) {  // pc 0..3: documents, 4..7: queries
+    auto load_piece = [&](uint32_t t, uint32_t slot0, uint32_t ks, uint32_t image, int pc) {  // pc 0..3: documents, 4..7: queries
         unsigned char* img = lds + image * IMG_BYTES + wv * 4096;
         if (pc < 4) {
             const int i = pc;
-            const __amdgpu_buffer_rsrc_t ares = doc_rsrc(t);
+            const __amdgpu_buffer_rsrc_t ares = doc_rsrc(t, slot0);
             const uint32_t kill = ks * 8 + dslot[i & 1] < a.row_vecs ? 0u : 0x40000000u;
             // nt: every document byte is read once per launch
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ares, (lds_ptr)(img + i * 1024), 16, (int)(dva[i & 1] | kill),
-                                                     (int)(ks * 128u + (wv * 4 + i) * 8u * row_bytes), 0, 2);
+            if constexpr (GATHER)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ares, (lds_ptr)(img + i * 1024), 16, (int)(gva[i] | kill),
+                                                         (int)(ks * 128u), 0, 2);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ares, (lds_ptr)(img + i * 1024), 16, (int)(dva[i & 1] | kill),
+                                                         (int)(ks * 128u + (wv * 4 + i) * 8u * row_bytes), 0, 2);
         } else {
             const int i = pc - 4;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(qres, (lds_ptr)(img + IMG_B + i * 1024), 16, (int)dvb[i & 1],
                                                      (int)(ks * 128u + (wv * 4 + i) * 8u * (KS * 128u)), 0, 0);
         }
     };
-    auto load_step = [&](uint32_t t, uint32_t ks, uint32_t image) {
+    auto load_step = [&](uint32_t t, uint32_t slot0, uint32_t ks, uint32_t image) {
 #pragma unroll
-        for (int pc = 0; pc < 8; ++pc) load_piece(t, ks, image, pc);
+        for (int pc = 0; pc < 8; ++pc) load_piece(t, slot0, ks, image, pc);
     };
     // the norms of tile t's rows into snorm[par] (one wave; rows past the end read 0)
     auto issue_norms = [&](uint32_t t, uint32_t par) {
         const bool live = t != TILE_NONE;
         const uint64_t row0 = live ? (uint64_t)t * BM : 0;
-        const uint64_t left = live && a.n_slots > row0 ? a.n_slots - row0 : 0;
+        const uint64_t left = live && n_rows > row0 ? n_rows - row0 : 0;
         const __amdgpu_buffer_rsrc_t nres = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(a.norms + row0), 0, (int)((left < (uint64_t)BM ? left : (uint64_t)BM) * 4), 0x00020000);
 #pragma unroll
@@ -743,12 +784,25 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
                                                      (int)(lane * 4u), i * 256, 0, 0);
     };
 
+    // GATHER: the slots of tile t's rows into smap[par] (one wave; the list is padded to whole tiles)
+    auto issue_map = [&](uint32_t t, uint32_t par) {
+        const bool live = t != TILE_NONE;
+        const __amdgpu_buffer_rsrc_t mres = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint32_t*>(a.map + (live ? (uint64_t)t * BM : 0)), 0, live ? BM * 4 : 0, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(mres, (lds_ptr)(lds + S_OFF_MAP + par * BM * 4 + i * 256), 4,
+                                                     (int)(lane * 4u), i * 256, 0, 0);
+    };
+
     uint32_t t0 = tile_at(0), t1 = tile_at(1);
+    uint32_t s0 = slot_at(0), s1 = slot_at(1);
     uint64_t w0[4];
     words_of(t0, w0);
+    if constexpr (GATHER) offsets_from(a.map + (uint64_t)t0 * BM, s0);  // (no load is in flight yet: waiting is free)
     if (wv == 7) issue_norms(t0, 0);
     uint32_t image = 0;  // the image the step about to be multiplied lies in
-    load_step(t0, 0, image);
+    load_step(t0, s0, 0, image);
 
     const uint32_t frag_a = swz(wm * 64 + r16, quarter), frag_b = IMG_B + swz(wn * 128 + r16, quarter);
     uint32_t t_prev = TILE_NONE;
@@ -796,9 +850,9 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
     read_a(lds, 0, fa[0]);
     read_b(lds, 0, 0, fb[0]);
     {
-        const uint32_t t_1 = 1 < KS ? t0 : t1, k_1 = 1 < KS ? 1u : 0u;
+        const uint32_t t_1 = 1 < KS ? t0 : t1, k_1 = 1 < KS ? 1u : 0u, s_1 = 1 < KS ? s0 : s1;
 #pragma unroll
-        for (int pc = 0; pc < 4; ++pc) load_piece(t_1, k_1, 1, pc);
+        for (int pc = 0; pc < 4; ++pc) load_piece(t_1, s_1, k_1, 1, pc);
     }
 
     // appends the queue of tile `t` (parity pp) to this workgroup's region; wave 0 only, which
@@ -811,7 +865,9 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
             if (lane == 0) *a.overflow = 1u;
             n = 0;
         }
-        for (uint32_t i = lane; i < n; i += 64) {
+        // (the lane number is taken afresh: hoisted out of the tile loop, this loop's addresses were
+        // the first thing the register allocator spilled)
+        for (uint32_t i = opaque(lane); i < n; i += 64) {
             const uint64_t e = queue[pp * QCAP + i];
             u32x4 out;
             out[0] = (uint32_t)(e >> 32);
@@ -830,7 +886,7 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
     for (uint32_t j = 0; j < n_mine; ++j) {
         const uint32_t par = j & 1;
         // tile ids two ahead and the next tile's words are requested now and used a tile later
-        const uint32_t t2 = tile_at(j + 2);
+        const uint32_t t2 = tile_at(j + 2), s2 = slot_at(j + 2);
         uint64_t w1[4];
         words_of(t1, w1);
 
@@ -849,25 +905,32 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
             // rows that are not candidates get a NaN norm: their t is NaN, which the running
             // maximum ignores
             const bool is_cand = (w0[tid >> 6] >> (tid & 63)) & 1;  // w0[] index is wave-uniform
-            const float pn = snorm[par * BM + tid];
+            const uint32_t me = opaque(tid);  // (address taken afresh per tile, or it is kept in a spilled register)
+            const float pn = snorm[par * BM + me];
             if (is_cand && !(pn < __builtin_inff())) *a.overflow = 1u;
-            if (!is_cand) snorm[par * BM + tid] = __builtin_nanf("");
+            if (!is_cand) snorm[par * BM + me] = __builtin_nanf("");
         }
         if (wv == 0 && j > 0) flush(t_prev, par ^ 1u);
-        if (wv == 7) issue_norms(t1, par ^ 1u);
+        if (wv == 7) {
+            issue_norms(t1, par ^ 1u);
+            if constexpr (GATHER) issue_map(t1, par ^ 1u);
+        }
 
         for (uint32_t ks = 0; ks < KS; ++ks) {
             const unsigned char* img = lds + image * IMG_BYTES;
             const uint32_t other = image ^ 1u;
             // (tile, step) of the next step and of the one after it (past the last tile: zeros)
             const uint32_t t_1 = ks + 1 < KS ? t0 : t1, k_1 = ks + 1 < KS ? ks + 1 : 0;
-            uint32_t t_2 = t0, k_2 = ks + 2;
+            const uint32_t s_1 = ks + 1 < KS ? s0 : s1;
+            uint32_t t_2 = t0, k_2 = ks + 2, s_2 = s0;
             if (k_2 >= KS) {
                 k_2 -= KS;
                 t_2 = t1;
-                if (k_2 >= KS) {  // one-step tiles
+                s_2 = s1;
+                if (k_2 >= KS) {  // one-step tiles (never in the GATHER build: its launcher wants three steps)
                     k_2 -= KS;
                     t_2 = t2;
+                    s_2 = s2;
                 }
             }
             auto multiply = [&](auto H, const bf16x8 (&xa)[4], const bf16x8 (&xb)[4]) {
@@ -891,8 +954,8 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
             read_b(img, 0, 1, fb[1]);
             __builtin_amdgcn_sched_barrier(0);
 #ifndef VS_ABL_NOLOAD
-            load_piece(t_1, k_1, other, 4);
-            load_piece(t_1, k_1, other, 5);
+            load_piece(t_1, s_1, k_1, other, 4);
+            load_piece(t_1, s_1, k_1, other, 5);
 #endif
             multiply(Int<0>{}, fa[0], fb[0]);
             __builtin_amdgcn_sched_barrier(0);
@@ -900,8 +963,8 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
             read_b(img, 1, 0, fb[0]);
             __builtin_amdgcn_sched_barrier(0);
 #ifndef VS_ABL_NOLOAD
-            load_piece(t_1, k_1, other, 6);
-            load_piece(t_1, k_1, other, 7);
+            load_piece(t_1, s_1, k_1, other, 6);
+            load_piece(t_1, s_1, k_1, other, 7);
 #endif
             multiply(Int<1>{}, fa[0], fb[1]);
             __builtin_amdgcn_sched_barrier(0);
@@ -919,9 +982,14 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
             read_a(lds + other * IMG_BYTES, 0, fa[0]);
             read_b(lds + other * IMG_BYTES, 0, 0, fb[0]);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (GATHER) {
+                // the rows about to be requested are the NEXT tile's from here on: its slots were
+                // staged at this tile's top and are visible since the first step's barrier
+                if (ks + 2 == KS) offsets_from(smap + (par ^ 1u) * BM, s1);
+            }
 #ifndef VS_ABL_NOLOAD
 #pragma unroll
-            for (int pc = 0; pc < 4; ++pc) load_piece(t_2, k_2, image, pc);
+            for (int pc = 0; pc < 4; ++pc) load_piece(t_2, s_2, k_2, image, pc);
 #endif
             multiply(Int<1>{}, fa[1], fb[1]);
             __builtin_amdgcn_sched_barrier(0);
@@ -981,6 +1049,8 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
         t_prev = t0;
         t0 = t1;
         t1 = t2;
+        s0 = s1;
+        s1 = s2;
 #pragma unroll
         for (int i = 0; i < 4; ++i) w0[i] = w1[i];
     }
@@ -1147,11 +1217,237 @@ __global__ __launch_bounds__(256) void prep_queries_bf16_kernel(const float* que
     if (lane == 0) qnorm[j] = sqrtf(s);
 }
 
+// ---- selective filters: the candidates gathered into a dense slab ----------------------------
+//
+// The matrix-core scan multiplies whole 256-row tiles, so under a filter that keeps one row in ten
+// it would still read and multiply all of them. Below a quarter of the rows the candidates are
+// copied once into a dense slab of their own (rows, norms, an all-ones present bitmap), in slot
+// order, the two passes above run on that slab, and the compact row numbers in their result are
+// turned back into docids. Slot order is kept, so ties still break by docid. Cost: the candidate
+// bytes are read twice and written once instead of every row being read once.
+
+namespace {
+
+constexpr uint32_t GATHER_BLOCK_WORDS = 256;  // mask words per workgroup of the counting kernels: one per thread
+
+__device__ __forceinline__ uint64_t candidate_word(const uint64_t* present, const uint64_t* cand, uint64_t i,
+                                                   uint64_t n_words) {
+    return i < n_words ? present[i] & cand[i] : 0ull;
+}
+
+// exclusive prefix sum over the 256 threads of a workgroup; *total = the sum
+__device__ __forceinline__ uint32_t block_exclusive_256(uint32_t v, uint32_t* wave_sums, uint32_t* total) {
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= (uint32_t)d) inc += o;
+    }
+    if (lane == 63) wave_sums[wv] = inc;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {
+        const uint32_t x = wave_sums[i];
+        if (i < wv) before += x;
+        all += x;
+    }
+    __syncthreads();
+    *total = all;
+    return before + inc - v;
+}
+
+}  // namespace
+
+// candidates per block of 256 mask words
+__global__ __launch_bounds__(256) void gather_count_kernel(const uint64_t* present, const uint64_t* cand,
+                                                           uint64_t n_words, uint32_t* block_sums) {
+    __shared__ uint32_t wave_sums[4];
+    const uint64_t wi = (uint64_t)blockIdx.x * GATHER_BLOCK_WORDS + threadIdx.x;
+    const uint32_t c = (uint32_t)__builtin_popcountll(candidate_word(present, cand, wi, n_words));
+    uint32_t total;
+    (void)block_exclusive_256(c, wave_sums, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// The sample of a candidate list of `tiles` tiles of 256: tiles 0, stride, 2 * stride, ... (`count`
+// of them), as plan_batch spreads the sample over a store.
+__host__ __device__ inline void sample_of(uint32_t tiles, uint32_t* stride, uint32_t* count) {
+    *count = tiles < (uint32_t)SAMPLE_TILES ? tiles : (uint32_t)SAMPLE_TILES;
+    uint32_t st = tiles / (uint32_t)SAMPLE_TILES;
+    if (st < 1) st = 1;
+    if (!(st & 1)) st -= 1;
+    *stride = st;
+}
+
+// block_sums -> exclusive offsets in place; head[0] = min(number of candidates, cap), head[1] = tiles
+// of 256 they fill, head[2], head[3] = the sample's stride and tile count. One workgroup.
+__global__ __launch_bounds__(256) void gather_scan_kernel(uint32_t* block_sums, uint32_t n_blocks, uint32_t cap,
+                                                          uint32_t* head) {
+    __shared__ uint32_t wave_sums[4];
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += 256) {
+        const uint32_t i = b0 + threadIdx.x;
+        const uint32_t v = i < n_blocks ? block_sums[i] : 0;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_256(v, wave_sums, &total);
+        if (i < n_blocks) block_sums[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t n = carry < cap ? carry : cap;
+        const uint32_t tiles = (uint32_t)(((uint64_t)n + BM - 1) / BM);
+        head[0] = n;
+        head[1] = tiles;
+        sample_of(tiles, head + 2, head + 3);
+    }
+}
+
+// map[i] = slot of the i-th candidate, in slot order (and its norm, if asked). A lane expands its
+// own word into a per-wave LDS list (as many steps as the fullest word has bits), and the wave
+// copies the list out with contiguous writes.
+__global__ __launch_bounds__(256) void gather_map_kernel(const uint64_t* present, const uint64_t* cand,
+                                                         uint64_t n_words, const uint32_t* block_offsets,
+                                                         uint32_t cap, uint32_t* map, const float* norms,
+                                                         float* norms_c /* nullable: norms in list order */) {
+    __shared__ uint16_t stage[4][4096];  // bit positions within the wave's 64 words
+    __shared__ uint32_t wave_sums[4];
+    const uint32_t lane = threadIdx.x & 63, wv = uniform_u32(threadIdx.x >> 6);
+    const uint64_t wave_word0 = (uint64_t)blockIdx.x * GATHER_BLOCK_WORDS + (uint64_t)wv * 64;
+    uint64_t x = candidate_word(present, cand, wave_word0 + lane, n_words);
+    const uint32_t c = (uint32_t)__builtin_popcountll(x);
+    uint32_t inc = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= (uint32_t)d) inc += o;
+    }
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    uint32_t o = inc - c;
+    while (x) {
+        stage[wv][o++] = (uint16_t)(lane * 64 + (uint32_t)__builtin_ctzll(x));
+        x &= x - 1;
+    }
+    if (lane == 0) wave_sums[wv] = total;
+    __syncthreads();
+    uint32_t at = block_offsets[blockIdx.x];
+    for (uint32_t i = 0; i < wv; ++i) at += wave_sums[i];
+    for (uint32_t i = lane; i < total; i += 64) {
+        const uint32_t pos = at + i;
+        if (pos < cap) {
+            const uint32_t slot = (uint32_t)(wave_word0 * 64) + stage[wv][i];
+            map[pos] = slot;
+            if (norms_c) norms_c[pos] = norms[slot];
+        }
+    }
+}
+
+// rows, norms and the present words of the dense slab; one thread per 16-byte vector
+__global__ __launch_bounds__(256) void gather_rows_kernel(const u32x4* rows, const float* norms, uint32_t row_vecs,
+                                                          const uint32_t* map, const uint32_t* head, u32x4* rows_c,
+                                                          float* norms_c, uint64_t* present_c) {
+    const uint32_t n = head[0];
+    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i = (uint32_t)(g / row_vecs), v = (uint32_t)(g - (uint64_t)i * row_vecs);
+    if (i >= n) return;
+    const uint32_t slot = map[i];
+    rows_c[g] = __builtin_nontemporal_load(rows + (uint64_t)slot * row_vecs + v);
+    if (v == 0) {
+        norms_c[i] = norms[slot];
+        if ((i & 63u) == 0) present_c[i >> 6] = n - i >= 64 ? ~0ull : (1ull << (n - i)) - 1ull;
+    }
+}
+
+// compact row numbers in the result back to docids
+__global__ __launch_bounds__(256) void gather_translate_kernel(const uint32_t* map, uint32_t docid_base, uint32_t total,
+                                                               uint64_t* keys, uint32_t* ids, const uint32_t* counts,
+                                                               uint32_t k, const uint32_t* skip_if_set) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total || (skip_if_set && *skip_if_set)) return;
+    if (keys) {
+        const uint64_t key = keys[i];
+        if (key != KEY_NONE) keys[i] = (key & 0xFFFFFFFF00000000ull) | (uint64_t)(docid_base + map[(uint32_t)key]);
+    }
+    if (ids && i % k < counts[i / k]) ids[i] = docid_base + map[ids[i]];
+}
+
+// ---- the same, without the copy: the streaming pass fetches the candidates where they lie -------
+//
+// scan_batch_stream_kernel<true> takes a tile's 256 rows from anywhere (one slot per row, staged in
+// LDS a tile ahead), so under a filter it reads exactly the candidates' bytes, once. Only the sample
+// (at most 65 536 rows) is copied into a dense slab, for the general kernel's unbounded first pass;
+// everything downstream works on positions in the candidate list, which the last launch turns
+// into docids. Needs three steps per tile or more (the offsets are swapped two steps before a tile
+// ends) and a tile's rows within GATHER_SPAN bytes of each other; a tile that is not raises
+// `overflow`, and then, as for anything else the streaming pass cannot hold, a gated unbounded scan
+// of the store itself produces the result.
+
+// pads the slot list to whole tiles with its last slot (rows that are not candidates, but valid addresses)
+__global__ __launch_bounds__(256) void gather_pad_kernel(uint32_t* map, const uint32_t* head) {
+    const uint32_t n = head[0];
+    const uint32_t i = n + threadIdx.x;
+    if (n != 0 && i < (n + BM - 1) / BM * BM) map[i] = map[n - 1];
+}
+
+// the sample tiles of the candidate list as a dense slab: rows, norms, present words
+__global__ __launch_bounds__(256) void gather_sample_kernel(const u32x4* rows, const float* norms, uint32_t row_vecs,
+                                                            const uint32_t* map, const uint32_t* head, u32x4* rows_s,
+                                                            float* norms_s, uint64_t* present_s) {
+    const uint32_t n = head[0], stride = head[2], count = head[3];
+    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i = (uint32_t)(g / row_vecs), v = (uint32_t)(g - (uint64_t)i * row_vecs);  // row i of the sample slab
+    const uint32_t j = i / (uint32_t)BM;
+    if (j >= count) return;
+    const uint64_t at = (uint64_t)j * stride * BM + (i & (uint32_t)(BM - 1));  // its place in the candidate list
+    if (at >= n) return;
+    const uint32_t slot = map[at];
+    rows_s[g] = __builtin_nontemporal_load(rows + (uint64_t)slot * row_vecs + v);
+    if (v == 0) {
+        norms_s[i] = norms[slot];
+        if ((i & 63u) == 0) present_s[i >> 6] = n - at >= 64 ? ~0ull : (1ull << (n - at)) - 1ull;
+    }
+}
+
+// sample slab row numbers in the sample's lists -> positions in the candidate list
+__global__ __launch_bounds__(256) void gather_sample_keys_kernel(uint64_t* keys, uint32_t total, const uint32_t* head) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const uint64_t key = keys[i];
+    if (key == KEY_NONE) return;
+    const uint32_t row = (uint32_t)key;
+    keys[i] = (key & 0xFFFFFFFF00000000ull) | (uint64_t)((row / (uint32_t)BM) * head[2] * (uint32_t)BM + (row & (uint32_t)(BM - 1)));
+}
+
+// The tiles of the candidate list outside the sample, each with the slot of its first row. A tile
+// whose rows lie further apart than the streaming pass can address is left out and raises `overflow`.
+__global__ __launch_bounds__(256) void batch_tiles_gather_kernel(const uint32_t* map, const uint32_t* head,
+                                                                 uint32_t row_bytes, uint32_t* tiles,
+                                                                 uint32_t* tile_count, uint32_t* overflow) {
+    const uint32_t n = head[0], n_tiles = head[1], stride = head[2], count = head[3];
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_tiles || (t % stride == 0 && t / stride < count)) return;
+    const uint64_t first = (uint64_t)t * BM;
+    const uint64_t last = first + BM <= n ? first + BM - 1 : (uint64_t)n - 1;
+    const uint32_t s0 = map[first];
+    if ((uint64_t)(map[last] - s0 + 1) * row_bytes > (uint64_t)GATHER_SPAN) {
+        *overflow = 1u;
+        return;
+    }
+    const uint32_t at = atomicAdd(tile_count, 1u);
+    tiles[2 * at] = t;
+    tiles[2 * at + 1] = s0;
+}
+
 namespace {
 
 struct BatchPlan {
     uint32_t ksteps, n_tiles, sample_tiles, sample_stride, blocks1, blocks2, cap;
     size_t off_qnorm, off_sample, off_partial1, off_partial2, off_counters, off_tiles, off_buckets, off_regions, total;
+    // the filtered form that fetches the candidates in place (three steps per tile or more)
+    bool in_place;
+    uint32_t fallback_blocks, gather_blocks;
+    size_t off_ghead, off_gsums, off_map, off_normsc, off_spresent, off_snorms, off_srows;
 };
 // counters: [0] tile count, [1] overflow flag, [2 .. 2 + 256) bucket fill, [258 .. 258 + 256) region fill
 constexpr uint32_t STREAM_GRID = 256;
@@ -1179,7 +1475,12 @@ BatchPlan plan_batch(const SlabView& s, uint32_t k) {
     p.off_partial1 = off;
     off += (size_t)BN * p.blocks1 * k * 8;
     p.off_partial2 = off;
-    off += (size_t)BN * (p.blocks2 + 1) * k * 8;
+    p.in_place = p.ksteps >= 3;
+    p.fallback_blocks = p.n_tiles < 256 ? p.n_tiles : 256;
+    {
+        const uint32_t lists = p.in_place && p.fallback_blocks > p.blocks2 + 1 ? p.fallback_blocks : p.blocks2 + 1;
+        off += (size_t)BN * lists * k * 8;
+    }
     // streaming second pass: a query expects k * rows / sample rows survivors (its bound is the k-th
     // best of the sample); buckets hold four times that, a power of two between 1024 and 65536
     const uint64_t sample_rows = (uint64_t)p.sample_tiles * BM;
@@ -1191,11 +1492,30 @@ BatchPlan plan_batch(const SlabView& s, uint32_t k) {
     p.off_counters = off;
     off += (size_t)N_COUNTERS * 4 + 256;
     p.off_tiles = off;
-    off += ((size_t)p.n_tiles * 4 + 255) / 256 * 256;
+    off += ((size_t)p.n_tiles * 8 + 255) / 256 * 256;
     p.off_buckets = off;
     off += (size_t)BN * cap * 8;
     p.off_regions = off;  // a workgroup's share of the survivors is a query's share: the same capacity
     off += (size_t)STREAM_GRID * cap * 16;
+    off = (off + 255) / 256 * 256;
+    p.gather_blocks = (uint32_t)(((s.n_slots >> 6) + GATHER_BLOCK_WORDS - 1) / GATHER_BLOCK_WORDS);
+    if (p.in_place) {
+        auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+        p.off_ghead = off;
+        off += 256;
+        p.off_gsums = off;
+        off += up((size_t)p.gather_blocks * 4);
+        p.off_map = off;
+        off += up(((size_t)s.n_slots + BM) * 4);
+        p.off_normsc = off;
+        off += up(((size_t)s.n_slots + BM) * 4);
+        p.off_spresent = off;
+        off += up((size_t)p.sample_tiles * BM / 8 + 64);
+        p.off_snorms = off;
+        off += up((size_t)p.sample_tiles * BM * 4);
+        p.off_srows = off;
+        off += up((size_t)p.sample_tiles * BM * s.row_vecs * 16);
+    }
     p.total = off + 256;
     return p;
 }
@@ -1203,6 +1523,11 @@ BatchPlan plan_batch(const SlabView& s, uint32_t k) {
 }  // namespace
 
 uint64_t batch_workspace_bytes(const SlabView& s, uint32_t k) { return plan_batch(s, k).total; }
+
+bool batch_filters_in_place(const SlabView& s) {
+    static const bool allowed = getenv("VS_BATCH_NO_GATHER") == nullptr;
+    return allowed && (s.row_vecs + 7) / 8 >= 3 && s.n_slots < 0xFFFFFF00ull;
+}
 
 hipError_t launch_scan_batch_bf16(const SlabView& s, const float* d_queries, uint32_t n_q,
                                   const uint64_t* cand, uint32_t k, void* workspace,
@@ -1249,6 +1574,108 @@ hipError_t launch_scan_batch_bf16(const SlabView& s, const float* d_queries, uin
     a.n_q = n_q;
     a.gate = nullptr;
 
+    if (cand && batch_filters_in_place(s)) {
+        // ---- under a filter: the candidates where they lie (see batch_tiles_gather_kernel) ----
+        uint32_t* head = reinterpret_cast<uint32_t*>(ws + p.off_ghead);
+        uint32_t* gsums = reinterpret_cast<uint32_t*>(ws + p.off_gsums);
+        uint32_t* map = reinterpret_cast<uint32_t*>(ws + p.off_map);
+        float* norms_c = reinterpret_cast<float*>(ws + p.off_normsc);
+        uint64_t* present_s = reinterpret_cast<uint64_t*>(ws + p.off_spresent);
+        float* norms_s = reinterpret_cast<float*>(ws + p.off_snorms);
+        u32x4* rows_s = reinterpret_cast<u32x4*>(ws + p.off_srows);
+        const uint64_t n_words = s.n_slots >> 6;
+        // sample slab rows past the candidates are not present, and their norms are defined
+        e = hipMemsetAsync(ws + p.off_spresent, 0, p.off_srows - p.off_spresent, stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(gather_count_kernel, dim3(p.gather_blocks), dim3(256), 0, stream, s.present, cand, n_words, gsums);
+        hipLaunchKernelGGL(gather_scan_kernel, dim3(1), dim3(256), 0, stream, gsums, p.gather_blocks, (uint32_t)s.n_slots,
+                           head);
+        hipLaunchKernelGGL(gather_map_kernel, dim3(p.gather_blocks), dim3(256), 0, stream, s.present, cand, n_words, gsums,
+                           (uint32_t)s.n_slots, map, s.norms, norms_c);
+        hipLaunchKernelGGL(gather_pad_kernel, dim3(1), dim3(256), 0, stream, map, head);
+        const uint64_t sample_vecs = (uint64_t)p.sample_tiles * BM * s.row_vecs;
+        hipLaunchKernelGGL(gather_sample_kernel, dim3((uint32_t)((sample_vecs + 255) / 256)), dim3(256), 0, stream, a.rows,
+                           s.norms, s.row_vecs, map, head, rows_s, norms_s, present_s);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        // the unbounded pass over the sample slab: lists of sample-slab row numbers -> list positions
+        BatchArgs f = a;
+        f.rows = rows_s;
+        f.norms = norms_s;
+        f.present = present_s;
+        f.cand = nullptr;
+        f.n_slots = (uint64_t)p.sample_tiles * BM;
+        f.docid_base = 0;
+        f.bound_keys = nullptr;
+        f.partial = partial1;
+        f.n_tiles = p.sample_tiles;
+        f.sample_stride = 1;
+        f.sample_count = p.sample_tiles;
+        f.pass = 1;
+        f.lists = p.blocks1;
+        hipLaunchKernelGGL(first, dim3(p.blocks1), dim3(BTHREADS), lds, stream, f);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        e = launch_merge_batch(partial1, p.blocks1, k, 1, n_q, (uint64_t)p.blocks1 * k, k, VS_ANGULAR, sample, nullptr,
+                               nullptr, nullptr, stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(gather_sample_keys_kernel, dim3((n_q * k + 255) / 256), dim3(256), 0, stream, sample, n_q * k, head);
+        // the streaming pass over the rest of the list
+        void (*gather_kernel)(StreamArgs) = scan_batch_stream_kernel<true>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(gather_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                S_LDS);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(batch_tiles_gather_kernel, dim3((p.n_tiles + 255) / 256), dim3(256), 0, stream, map, head,
+                           s.row_vecs * 16u, tiles, counters, counters + 1);
+        StreamArgs sa;
+        sa.rows = a.rows;
+        sa.norms = norms_c;
+        sa.present = s.present;
+        sa.cand = cand;
+        sa.qrows = a.qrows;
+        sa.qnorm = qnorm;
+        sa.bound_keys = sample;
+        sa.tiles = tiles;
+        sa.tile_count = counters;
+        sa.regions = regions;
+        sa.region_count = counters + 2 + BN;
+        sa.overflow = counters + 1;
+        sa.n_slots = s.n_slots;
+        sa.row_vecs = s.row_vecs;
+        sa.ksteps = p.ksteps;
+        sa.docid_base = 0;
+        sa.k = k;
+        sa.n_q = n_q;
+        sa.cap = p.cap;
+        sa.map = map;
+        sa.head = head;
+        hipLaunchKernelGGL(gather_kernel, dim3(STREAM_GRID), dim3(BTHREADS), S_LDS, stream, sa);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(batch_bucket_kernel, dim3(STREAM_GRID), dim3(256), 0, stream, regions, counters + 2 + BN,
+                           p.cap, buckets, counters + 2, counters + 1);
+        hipLaunchKernelGGL(batch_select_kernel, dim3(n_q), dim3(256), (size_t)4 * k * 8, stream, buckets, counters + 2,
+                           p.cap, sample, norms_c, qnorm, 0u, k, out_keys, out_ids, out_dist, out_n);
+        hipLaunchKernelGGL(gather_translate_kernel, dim3((n_q * k + 255) / 256), dim3(256), 0, stream, map, s.docid_base,
+                           n_q * k, out_keys, out_ids, out_n, k, counters + 1);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        // ... and, only where something raised `overflow`, one unbounded scan of the store itself
+        a.gate = counters + 1;
+        a.bound_keys = nullptr;
+        a.partial = partial2;
+        a.n_tiles = p.n_tiles;
+        a.sample_stride = 1;
+        a.sample_count = 0;
+        a.pass = 2;
+        a.lists = p.fallback_blocks;
+        hipLaunchKernelGGL(kernel, dim3(p.fallback_blocks), dim3(BTHREADS), lds, stream, a);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        return launch_merge_batch(partial2, p.fallback_blocks, k, 1, n_q, (uint64_t)p.fallback_blocks * k, k, VS_ANGULAR,
+                                  out_keys, out_ids, out_dist, out_n, stream, a.gate);
+    }
+
     // pass 1: the first tiles, no bound
     const bool two = p.blocks2 > 0;
     a.bound_keys = nullptr;
@@ -1271,7 +1698,7 @@ hipError_t launch_scan_batch_bf16(const SlabView& s, const float* d_queries, uin
     static const bool use_stream = getenv("VS_BATCH_NO_STREAM") == nullptr;  // measurement switch
     if (use_stream) {
         StreamArgs sa;
-        void (*stream_kernel)(StreamArgs) = scan_batch_stream_kernel;
+        void (*stream_kernel)(StreamArgs) = scan_batch_stream_kernel<false>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(stream_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS);
         if (e != hipSuccess) return e;
@@ -1296,6 +1723,8 @@ hipError_t launch_scan_batch_bf16(const SlabView& s, const float* d_queries, uin
         sa.k = k;
         sa.n_q = n_q;
         sa.cap = p.cap;
+        sa.map = nullptr;
+        sa.head = nullptr;
         hipLaunchKernelGGL(stream_kernel, dim3(STREAM_GRID), dim3(BTHREADS), S_LDS, stream, sa);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
@@ -1318,134 +1747,6 @@ hipError_t launch_scan_batch_bf16(const SlabView& s, const float* d_queries, uin
                               out_keys, out_ids, out_dist, out_n, stream, a.gate);
 }
 
-
-// ---- selective filters: the candidates gathered into a dense slab ----------------------------
-//
-// The matrix-core scan multiplies whole 256-row tiles, so under a filter that keeps one row in ten
-// it would still read and multiply all of them. Below a quarter of the rows the candidates are
-// copied once into a dense slab of their own (rows, norms, an all-ones present bitmap), in slot
-// order, the two passes above run on that slab, and the compact row numbers in their result are
-// turned back into docids. Slot order is kept, so ties still break by docid. Cost: the candidate
-// bytes are read twice and written once instead of every row being read once.
-
-namespace {
-
-constexpr uint32_t GATHER_BLOCK_WORDS = 1024;  // mask words per workgroup of the counting kernels: 256 threads x 4
-
-__device__ __forceinline__ uint64_t candidate_word(const uint64_t* present, const uint64_t* cand, uint64_t i,
-                                                   uint64_t n_words) {
-    return i < n_words ? present[i] & cand[i] : 0ull;
-}
-
-// exclusive prefix sum over the 256 threads of a workgroup; *total = the sum
-__device__ __forceinline__ uint32_t block_exclusive_256(uint32_t v, uint32_t* wave_sums, uint32_t* total) {
-    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(inc, d, 64);
-        if (lane >= (uint32_t)d) inc += o;
-    }
-    if (lane == 63) wave_sums[wv] = inc;
-    __syncthreads();
-    uint32_t before = 0, all = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < 4; ++i) {
-        const uint32_t x = wave_sums[i];
-        if (i < wv) before += x;
-        all += x;
-    }
-    __syncthreads();
-    *total = all;
-    return before + inc - v;
-}
-
-}  // namespace
-
-// candidates per block of 1024 mask words
-__global__ __launch_bounds__(256) void gather_count_kernel(const uint64_t* present, const uint64_t* cand,
-                                                           uint64_t n_words, uint32_t* block_sums) {
-    __shared__ uint32_t wave_sums[4];
-    const uint64_t w0 = (uint64_t)blockIdx.x * GATHER_BLOCK_WORDS + (uint64_t)threadIdx.x * 4;
-    uint32_t c = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) c += (uint32_t)__builtin_popcountll(candidate_word(present, cand, w0 + j, n_words));
-    uint32_t total;
-    (void)block_exclusive_256(c, wave_sums, &total);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
-}
-
-// block_sums -> exclusive offsets in place; head[0] = min(number of candidates, cap). One workgroup.
-__global__ __launch_bounds__(256) void gather_scan_kernel(uint32_t* block_sums, uint32_t n_blocks, uint32_t cap,
-                                                          uint32_t* head) {
-    __shared__ uint32_t wave_sums[4];
-    uint32_t carry = 0;
-    for (uint32_t b0 = 0; b0 < n_blocks; b0 += 256) {
-        const uint32_t i = b0 + threadIdx.x;
-        const uint32_t v = i < n_blocks ? block_sums[i] : 0;
-        uint32_t total;
-        const uint32_t ex = block_exclusive_256(v, wave_sums, &total);
-        if (i < n_blocks) block_sums[i] = carry + ex;
-        carry += total;
-    }
-    if (threadIdx.x == 0) head[0] = carry < cap ? carry : cap;
-}
-
-// map[i] = slot of the i-th candidate, in slot order
-__global__ __launch_bounds__(256) void gather_map_kernel(const uint64_t* present, const uint64_t* cand,
-                                                         uint64_t n_words, const uint32_t* block_offsets,
-                                                         uint32_t cap, uint32_t* map) {
-    __shared__ uint32_t wave_sums[4];
-    const uint64_t w0 = (uint64_t)blockIdx.x * GATHER_BLOCK_WORDS + (uint64_t)threadIdx.x * 4;
-    uint64_t w[4];
-    uint32_t c = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        w[j] = candidate_word(present, cand, w0 + j, n_words);
-        c += (uint32_t)__builtin_popcountll(w[j]);
-    }
-    uint32_t total;
-    uint32_t at = block_offsets[blockIdx.x] + block_exclusive_256(c, wave_sums, &total);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        uint64_t x = w[j];
-        while (x) {
-            const uint32_t bit = (uint32_t)__builtin_ctzll(x);
-            x &= x - 1;
-            if (at < cap) map[at] = (uint32_t)((w0 + j) * 64 + bit);
-            ++at;
-        }
-    }
-}
-
-// rows, norms and the present words of the dense slab; one thread per 16-byte vector
-__global__ __launch_bounds__(256) void gather_rows_kernel(const u32x4* rows, const float* norms, uint32_t row_vecs,
-                                                          const uint32_t* map, const uint32_t* head, u32x4* rows_c,
-                                                          float* norms_c, uint64_t* present_c) {
-    const uint32_t n = head[0];
-    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint32_t i = (uint32_t)(g / row_vecs), v = (uint32_t)(g - (uint64_t)i * row_vecs);
-    if (i >= n) return;
-    const uint32_t slot = map[i];
-    rows_c[g] = __builtin_nontemporal_load(rows + (uint64_t)slot * row_vecs + v);
-    if (v == 0) {
-        norms_c[i] = norms[slot];
-        if ((i & 63u) == 0) present_c[i >> 6] = n - i >= 64 ? ~0ull : (1ull << (n - i)) - 1ull;
-    }
-}
-
-// compact row numbers in the result back to docids
-__global__ __launch_bounds__(256) void gather_translate_kernel(const uint32_t* map, uint32_t docid_base, uint32_t total,
-                                                               uint64_t* keys, uint32_t* ids, const uint32_t* counts,
-                                                               uint32_t k) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    if (keys) {
-        const uint64_t key = keys[i];
-        if (key != KEY_NONE) keys[i] = (key & 0xFFFFFFFF00000000ull) | (uint64_t)(docid_base + map[(uint32_t)key]);
-    }
-    if (ids && i % k < counts[i / k]) ids[i] = docid_base + map[ids[i]];
-}
 
 namespace {
 
@@ -1521,7 +1822,7 @@ hipError_t launch_scan_batch_bf16_gathered(const SlabView& s, const float* d_que
     hipLaunchKernelGGL(gather_count_kernel, dim3(g.n_blocks), dim3(256), 0, stream, s.present, cand, n_words, block_sums);
     hipLaunchKernelGGL(gather_scan_kernel, dim3(1), dim3(256), 0, stream, block_sums, g.n_blocks, (uint32_t)g.cap, head);
     hipLaunchKernelGGL(gather_map_kernel, dim3(g.n_blocks), dim3(256), 0, stream, s.present, cand, n_words, block_sums,
-                       (uint32_t)g.cap, map);
+                       (uint32_t)g.cap, map, s.norms, static_cast<float*>(nullptr));
     const uint64_t vecs = g.cap * s.row_vecs;
     hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)((vecs + 255) / 256)), dim3(256), 0, stream,
                        reinterpret_cast<const u32x4*>(s.rows), s.norms, s.row_vecs, map, head, rows_c, norms_c, present_c);
@@ -1537,7 +1838,7 @@ hipError_t launch_scan_batch_bf16_gathered(const SlabView& s, const float* d_que
     if (e != hipSuccess) return e;
     const uint32_t total = n_q * k;
     hipLaunchKernelGGL(gather_translate_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, map, s.docid_base, total,
-                       out_keys, out_ids, out_n, k);
+                       out_keys, out_ids, out_n, k, static_cast<const uint32_t*>(nullptr));
     return hipGetLastError();
 }
 

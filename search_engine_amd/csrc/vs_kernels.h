@@ -103,6 +103,10 @@ hipError_t launch_scan_batch_bf16(const SlabView& s, const float* d_queries, uin
                                   const uint64_t* cand, uint32_t k, void* workspace,
                                   uint64_t* out_keys, uint32_t* out_ids, float* out_dist,
                                   uint32_t* out_n, hipStream_t stream);
+// True if launch_scan_batch_bf16 itself reads only the candidates of a filter (rows of more than 128
+// elements: the streaming pass fetches them where they lie); otherwise it multiplies whole 256-row
+// tiles, and the gathered form below pays under selective filters.
+bool batch_filters_in_place(const SlabView& s);
 // The same search under a selective filter: the candidates (present & cand, at most `max_candidates`
 // of them: any upper bound; rows beyond it would be dropped) are first gathered into a dense slab inside
 // `workspace` (batch_gather_workspace_bytes), in slot order, so that the scan reads and multiplies only

@@ -314,13 +314,14 @@ int32_t run_batch_and_fetch(vs_store* s, const vs::SlabView& v, Workspace* ws, c
     const size_t chunk_q = VS_BATCH_MAX_QUERIES;
     const size_t q_bytes = chunk_q * s->dim * 4;
     const size_t res_bytes = chunk_q * k * 8 + chunk_q * 4;  // ids, distances, counts
-    // Under a filter that keeps at most a quarter of the rows the candidates are gathered into a
-    // dense slab first (the matrix-core scan works on whole 256-row tiles; gathered, it reads the
-    // candidate bytes three times instead of every row once). Their number decides, so it is
-    // counted on the device: one small launch and one wait per call.
+    // Rows of up to 128 elements (two steps per tile): the scan multiplies whole 256-row tiles, so
+    // under a filter that keeps at most a quarter of the rows the candidates are gathered into a
+    // dense slab first (it then reads the candidate bytes three times instead of every row once).
+    // Their number decides, so it is counted on the device: one small launch and one wait per
+    // call. Longer rows need none of this: the scan fetches the candidates where they lie.
     uint64_t n_cand = 0;
     static const bool gather_allowed = getenv("VS_BATCH_NO_GATHER") == nullptr;  // measurement switch
-    if (d_cand && gather_allowed) {
+    if (d_cand && gather_allowed && !vs::batch_filters_in_place(v)) {
         if (int32_t rc = grow(&ws->d_partial, &ws->partial_bytes, (size_t)vs::count_candidates_workspace_bytes(v)))
             return rc;
         HIP_TRY(vs::launch_count_candidates(v, d_cand, reinterpret_cast<uint32_t*>(ws->d_partial), ws->d_n, ws->stream));

@@ -247,3 +247,32 @@ def test_batch_device_api_sharded(gpu_ctx):
     finally:
         for st in (whole, a, b):
             st.destroy()
+
+
+@pytest.mark.parametrize("dim,pass_percent", [(192, 25), (768, 3), (200, 60)])
+def test_batch_fetches_the_candidates_of_a_filter_in_place(gpu_ctx, dim, pass_percent):
+    """Rows of more than 128 elements: under a filter the streaming pass takes a tile's 256 rows from
+    wherever the candidates lie (three steps per tile or more, the offsets swapped two steps before a
+    tile ends). 25 % of 400 k rows fill more tiles than the sample, 3 % of 100 k fewer; dim 200 has a
+    K tail. Planted near-duplicates in and outside the filter, identical rows, a zero row."""
+    n = 256 * 256 * 6 + 64 * 5 if pass_percent != 3 else 100_000
+    base = 64 * 2
+    vectors = synthetic_vectors(n, dim, 0x1A + dim)
+    queries = synthetic_vectors(21, dim, 0x1B + dim)
+    rng = np.random.default_rng(dim)
+    keep = rng.random(n) < pass_percent / 100
+    for j in range(queries.shape[0]):
+        for pos in rng.choice(n, 8, replace=False):
+            vectors[pos] = queries[j] + 0.05 * rng.standard_normal(dim).astype(np.float32)
+    vectors[7000:7020] = vectors[6999]
+    keep[6999:7020] = True
+    queries[1] = vectors[6999] * 0.5
+    vectors[n - 3] = 0.0
+    keep[n - 3] = True
+    docids = np.arange(n, dtype=np.uint32) + base
+    mask = oracle.bool_to_mask(np.concatenate([np.zeros(base, bool), keep]))
+    store = make_bf16_store(gpu_ctx, vectors, docids, docid_base=base)
+    try:
+        check_batch(store, vectors, queries, 10, mask, docids)
+    finally:
+        store.destroy()
