@@ -397,7 +397,8 @@ def main():
 
         def recorded_batch_traffic():
             """The same for one batched bf16 call (every kernel of it), profiles/scan_traffic_bf16_batch256.json."""
-            tpath = os.path.join(ROOT, "profiles", f"scan_traffic_bf16_batch{n_q}.json")
+            sfx = "" if args.pass_percent == 100 else f"_p{args.pass_percent}"
+            tpath = os.path.join(ROOT, "profiles", f"scan_traffic_bf16_batch{n_q}{sfx}.json")
             if not os.path.exists(tpath):
                 return None
             with open(tpath) as f:
@@ -441,9 +442,12 @@ def main():
             line["metric"] = f"batched top-{k} vector QPS, {n_q} queries per step sharing passes over the rows"
             ms = head["step_kernel_ms"]
             if args.dtype == "bf16" and k <= 32:
-                # one pass over the shard on the matrix cores; a launch always computes 256 query columns
-                algo = n_local * (row_bytes + 4) + n_slots // 8
-                flop = 2.0 * n_local * dim * 256
+                # one pass over the shard on the matrix cores; a launch always computes 256 query columns.
+                # Rows of more than 128 elements are fetched where the candidates lie (only they are read and
+                # multiplied); shorter rows go through whole 256-row tiles.
+                rows_read = head["n_pass"] if dim > 128 else n_local
+                algo = rows_read * (row_bytes + 4) + n_slots // 8
+                flop = 2.0 * rows_read * dim * 256
                 line["roofline"] = {
                     "bound": "hbm", "achieved": round(algo / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),

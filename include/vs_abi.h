@@ -252,12 +252,12 @@ int32_t vs_search_mask(vs_store* s, const float* query, uint32_t dim, uint32_t k
  * bf16 up to 1536 dimensions) share each pass over the rows when k <= 128, and
  * every query's result is bit-identical to its own vs_search; on binary stores
  * (rows of up to 2048 bits, k <= 128) four queries share a pass, results equal
- * to vs_search's; anything else is one scan per query. On the matrix-core path a
- * filter that keeps at most a quarter of the items has its candidates copied
- * into a dense slab first (inside the call's own workspace: up to a quarter of
- * the store's bytes), so that only they are read and multiplied; the result is
- * the same. No reference counterpart (the reference searches one vector per
- * request). */
+ * to vs_search's; anything else is one scan per query. On the matrix-core path
+ * only the filter's candidates are read and multiplied: rows of more than 128
+ * dimensions are fetched where they lie; shorter rows, under a filter that keeps
+ * at most a quarter of the items, are first copied into a dense slab inside the
+ * call's own workspace. The result is the same either way. No reference
+ * counterpart (the reference searches one vector per request). */
 int32_t vs_search_batch(vs_store* s, const float* queries, uint32_t n_q, uint32_t dim,
                         uint32_t k, const uint64_t* mask_words, uint64_t n_mask_words,
                         uint32_t* out_ids, float* out_dist, uint32_t* out_n);
@@ -318,7 +318,8 @@ int32_t vs_search_device_noalloc(vs_store* s, const void* d_query, uint32_t dim,
  * memory) under one candidate mask; d_out_keys receives n_q lists of k keys.
  *   - angular VS_BF16 stores, k <= VS_BATCH_MAX_K: ONE pass over the rows on the
  *     matrix cores (queries rounded to bf16 on the device, so the distances are
- *     those of the rounded queries);
+ *     those of the rounded queries); with a mask and rows of more than 128
+ *     dimensions, over the candidates only;
  *   - f32 angular / dot-product stores of up to 768 dimensions, k <= 32, 17 or
  *     more queries: 32 per pass on the f32 matrix cores (distances equal
  *     vs_search_device's up to rounding);

@@ -37,7 +37,10 @@
 //
 // The launcher runs two passes: 256 tiles spread evenly over the store without a
 // bound, a merge that turns their lists into the per-query k-th best of that
-// sample, and the rest of the store with it as the bound.
+// sample, and the rest of the store with it as the bound. With a candidate mask and rows of
+// three steps or more the tiles are not tiles of the store but of the list of candidates: the
+// streaming pass fetches each tile's 256 rows from wherever they lie (its gathered build), so a
+// filter costs what its candidates cost.
 #include "vs_kernels.h"
 
 #include <stdlib.h>
@@ -1324,8 +1327,9 @@ __global__ __launch_bounds__(256) void gather_map_kernel(const uint64_t* present
         if (lane >= (uint32_t)d) inc += o;
     }
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    const bool all_rows = total == 4096;  // wave-uniform: 64 full words need no list, row i is candidate i
     uint32_t o = inc - c;
-    while (x) {
+    while (x && !all_rows) {
         stage[wv][o++] = (uint16_t)(lane * 64 + (uint32_t)__builtin_ctzll(x));
         x &= x - 1;
     }
@@ -1336,7 +1340,7 @@ __global__ __launch_bounds__(256) void gather_map_kernel(const uint64_t* present
     for (uint32_t i = lane; i < total; i += 64) {
         const uint32_t pos = at + i;
         if (pos < cap) {
-            const uint32_t slot = (uint32_t)(wave_word0 * 64) + stage[wv][i];
+            const uint32_t slot = (uint32_t)(wave_word0 * 64) + (all_rows ? i : (uint32_t)stage[wv][i]);
             map[pos] = slot;
             if (norms_c) norms_c[pos] = norms[slot];
         }
