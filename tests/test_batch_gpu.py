@@ -171,9 +171,11 @@ def test_batch_under_a_selective_filter_gathers_the_candidates(gpu_ctx):
         store.destroy()
 
 
-def test_batch_under_a_filter_of_a_few_rows(gpu_ctx):
-    """Three candidates (fewer than k, fewer than a tile), then candidates that are not items."""
-    n, dim = 5000, 32
+@pytest.mark.parametrize("dim", [32, 192])
+def test_batch_under_a_filter_of_a_few_rows(gpu_ctx, dim):
+    """Three candidates (fewer than k, fewer than a tile), then candidates that are not items; short
+    rows (the copied form) and long ones (fetched in place)."""
+    n = 5000
     rng = np.random.default_rng(3)
     docids = np.sort(rng.choice(9000, n, replace=False)).astype(np.uint32)
     vectors = synthetic_vectors(n, dim, 31)
@@ -249,12 +251,15 @@ def test_batch_device_api_sharded(gpu_ctx):
             st.destroy()
 
 
-@pytest.mark.parametrize("dim,pass_percent", [(192, 25), (768, 3), (200, 60)])
-def test_batch_fetches_the_candidates_of_a_filter_in_place(gpu_ctx, dim, pass_percent):
+@pytest.mark.parametrize("dim,pass_percent,k,awkward", [(192, 25, 10, False), (768, 3, 10, False), (200, 60, 10, False),
+                                                        (192, 25, 32, False), (192, 25, 10, True)])
+def test_batch_fetches_the_candidates_of_a_filter_in_place(gpu_ctx, dim, pass_percent, k, awkward):
     """Rows of more than 128 elements: under a filter the streaming pass takes a tile's 256 rows from
     wherever the candidates lie (three steps per tile or more, the offsets swapped two steps before a
     tile ends). 25 % of 400 k rows fill more tiles than the sample, 3 % of 100 k fewer; dim 200 has a
-    K tail. Planted near-duplicates in and outside the filter, identical rows, a zero row."""
+    K tail; k = 32 takes the staged build of the sample pass. Planted near-duplicates in and outside
+    the filter, identical rows, a zero row. awkward: a zero query and non-finite candidate rows make
+    the streaming pass give up, and the gated unbounded scan of the store itself delivers."""
     n = 256 * 256 * 6 + 64 * 5 if pass_percent != 3 else 100_000
     base = 64 * 2
     vectors = synthetic_vectors(n, dim, 0x1A + dim)
@@ -269,10 +274,15 @@ def test_batch_fetches_the_candidates_of_a_filter_in_place(gpu_ctx, dim, pass_pe
     queries[1] = vectors[6999] * 0.5
     vectors[n - 3] = 0.0
     keep[n - 3] = True
+    if awkward:
+        vectors[150000, 0] = np.inf
+        vectors[150300, 3] = np.nan
+        keep[[150000, 150300]] = True
+        queries[5] = 0.0
     docids = np.arange(n, dtype=np.uint32) + base
     mask = oracle.bool_to_mask(np.concatenate([np.zeros(base, bool), keep]))
     store = make_bf16_store(gpu_ctx, vectors, docids, docid_base=base)
     try:
-        check_batch(store, vectors, queries, 10, mask, docids)
+        check_batch(store, vectors, queries, k, mask, docids)
     finally:
         store.destroy()
