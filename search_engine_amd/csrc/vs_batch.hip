@@ -1536,7 +1536,9 @@ bool batch_filters_in_place(const SlabView& s) {
 hipError_t launch_scan_batch_bf16(const SlabView& s, const float* d_queries, uint32_t n_q,
                                   const uint64_t* cand, uint32_t k, void* workspace,
                                   uint64_t* out_keys, uint32_t* out_ids, float* out_dist,
-                                  uint32_t* out_n, hipStream_t stream) {
+                                  uint32_t* out_n, hipStream_t stream, bool whole_tiles,
+                                  const uint32_t** d_candidates) {
+    if (d_candidates) *d_candidates = nullptr;
     if (s.dtype != VS_BF16 || s.metric != VS_ANGULAR || k == 0 || k > VS_BATCH_MAX_K || n_q == 0 || n_q > (uint32_t)BN ||
         (s.n_slots & 63) != 0 || s.n_slots == 0)
         return hipErrorInvalidValue;
@@ -1578,9 +1580,20 @@ hipError_t launch_scan_batch_bf16(const SlabView& s, const float* d_queries, uin
     a.n_q = n_q;
     a.gate = nullptr;
 
-    if (cand && batch_filters_in_place(s)) {
+    if (cand && batch_filters_in_place(s) && whole_tiles) {
+        // the caller knows that the filter excludes next to nothing: the tiles of the store, below;
+        // the candidates are counted all the same, so that the caller sees when that changes
+        uint32_t* head = reinterpret_cast<uint32_t*>(ws + p.off_ghead);
+        uint32_t* gsums = reinterpret_cast<uint32_t*>(ws + p.off_gsums);
+        hipLaunchKernelGGL(gather_count_kernel, dim3(p.gather_blocks), dim3(256), 0, stream, s.present, cand,
+                           s.n_slots >> 6, gsums);
+        hipLaunchKernelGGL(gather_scan_kernel, dim3(1), dim3(256), 0, stream, gsums, p.gather_blocks, (uint32_t)s.n_slots,
+                           head);
+        if (d_candidates) *d_candidates = head;
+    } else if (cand && batch_filters_in_place(s)) {
         // ---- under a filter: the candidates where they lie (see batch_tiles_gather_kernel) ----
         uint32_t* head = reinterpret_cast<uint32_t*>(ws + p.off_ghead);
+        if (d_candidates) *d_candidates = head;
         uint32_t* gsums = reinterpret_cast<uint32_t*>(ws + p.off_gsums);
         uint32_t* map = reinterpret_cast<uint32_t*>(ws + p.off_map);
         float* norms_c = reinterpret_cast<float*>(ws + p.off_normsc);

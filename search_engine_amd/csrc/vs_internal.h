@@ -151,6 +151,18 @@ struct vs_store {
     std::atomic<uint64_t> sealed_items{0};
     std::atomic<bool> sealed{false};
 
+    // ---- batched device searches under a mask: what the last one counted (guarded by hint_mu).
+    // The batched matrix-core scan fetches a filter's candidates where they lie, which costs a few
+    // small launches more than multiplying whole tiles; under a mask that excludes next to nothing
+    // the whole tiles win. A device-API call cannot wait for a count, so it uses the one its
+    // predecessor under the same mask address left behind. The result never depends on it.
+    std::mutex hint_mu;
+    const void* hint_mask = nullptr;   // mask of the newest count requested
+    uint32_t* hint_count = nullptr;    // pinned host word the counts are copied to
+    hipEvent_t hint_event = nullptr;   // behind the newest copy
+    const void* known_mask = nullptr;  // newest count seen to have arrived (calls queued back to back never see their
+    uint64_t known_count = 0;          // predecessor's: they go by the last one that had, e.g. a warm-up call's)
+
     // geometry plus the given present buffer
     vs::SlabView view(int buf) const {
         vs::SlabView v;

@@ -99,10 +99,15 @@ hipError_t launch_scan_hamming_multi(const SlabView& s, const void* d_queries, u
 // batch_workspace_bytes bytes. Outputs as n_q consecutive blocks of k entries:
 // out_keys (nullable), out_ids / out_dist / out_n (nullable as a group).
 uint64_t batch_workspace_bytes(const SlabView& s, uint32_t k);
+// whole_tiles: under a mask, multiply the store's tiles anyway instead of fetching the candidates
+// where they lie (pays when the mask excludes next to nothing). *d_candidates (nullable) receives
+// the device address of the number of candidates the call counts on the stream, or null if it
+// counts none (no mask, or rows too short to be fetched in place).
 hipError_t launch_scan_batch_bf16(const SlabView& s, const float* d_queries, uint32_t n_q,
                                   const uint64_t* cand, uint32_t k, void* workspace,
                                   uint64_t* out_keys, uint32_t* out_ids, float* out_dist,
-                                  uint32_t* out_n, hipStream_t stream);
+                                  uint32_t* out_n, hipStream_t stream, bool whole_tiles = false,
+                                  const uint32_t** d_candidates = nullptr);
 // True if launch_scan_batch_bf16 itself reads only the candidates of a filter (rows of more than 128
 // elements: the streaming pass fetches them where they lie); otherwise it multiplies whole 256-row
 // tiles, and the gathered form below pays under selective filters.

@@ -743,6 +743,8 @@ extern "C" int32_t vs_store_destroy(vs_store* s) {
     }
     for (int i = 0; i < 2; ++i)
         for (auto& kv : s->stream_events[i]) (void)hipEventDestroy(kv.second);
+    if (s->hint_event) (void)hipEventDestroy(s->hint_event);
+    if (s->hint_count) (void)hipHostFree(s->hint_count);
     if (s->d_rows) (void)hipFree(s->d_rows);
     if (s->d_norms) (void)hipFree(s->d_norms);
     if (s->d_present[0]) (void)hipFree(s->d_present[0]);
@@ -1337,8 +1339,33 @@ int32_t launch_batch(vs_store* s, const vs::SlabView& v, const vs::ScanTuning& t
                      uint32_t n_q, uint32_t k, const uint64_t* d_mask_words, void* d_workspace,
                      uint64_t* d_out_keys, hipStream_t stream) {
     if (on_matrix_cores(s, k)) {
+        // whole tiles if the previous call under this mask counted so many candidates that skipping
+        // the rest would save less than the extra launches of the gathered form cost (~80 us of HBM time)
+        bool whole_tiles = false;
+        const bool counted = d_mask_words && vs::batch_filters_in_place(v);
+        if (counted) {
+            std::lock_guard<std::mutex> lk(s->hint_mu);
+            if (s->hint_event && hipEventQuery(s->hint_event) == hipSuccess) {
+                s->known_mask = s->hint_mask;
+                s->known_count = *s->hint_count;
+            }
+            if (s->known_mask == d_mask_words) {
+                const uint64_t n = s->known_count < v.n_slots ? s->known_count : v.n_slots;
+                whole_tiles = (v.n_slots - n) * s->row_bytes() < 350000000ull;
+            }
+        }
+        const uint32_t* d_count = nullptr;
         HIP_TRY(vs::launch_scan_batch_bf16(v, static_cast<const float*>(d_queries), n_q, d_mask_words, k,
-                                           d_workspace, d_out_keys, nullptr, nullptr, nullptr, stream));
+                                           d_workspace, d_out_keys, nullptr, nullptr, nullptr, stream, whole_tiles,
+                                           &d_count));
+        if (counted && d_count) {
+            std::lock_guard<std::mutex> lk(s->hint_mu);
+            if (!s->hint_count) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->hint_count), 64, hipHostMallocDefault));
+            if (!s->hint_event) HIP_TRY(hipEventCreateWithFlags(&s->hint_event, hipEventDisableTiming));
+            HIP_TRY(hipMemcpyAsync(s->hint_count, d_count, 4, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipEventRecord(s->hint_event, stream));
+            s->hint_mask = d_mask_words;
+        }
         return VS_OK;
     }
     if (vs::scan_hamming_multi_serves(v, k)) {
