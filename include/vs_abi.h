@@ -302,8 +302,9 @@ int32_t vs_search_device(vs_store* s, const void* d_query, uint32_t dim, uint32_
  * d_out_keys as vs_search_device, minus d_workspace: the scan's partial lists go
  * to a static array of VS_NOALLOC_SCRATCH_BYTES in device memory (one per GPU,
  * held until the process ends). The call allocates nothing and frees nothing.
- * Limit: (workgroups of the scan, at most 512 by default) * k * 8 bytes must fit,
- * i.e. k <= 256 on a large store; beyond that VS_E_CAPACITY. Every call on one
+ * Limit: (workgroups of the scan: by default at most 512, 1024 over float rows of
+ * 1 KiB or less) * k * 8 bytes must fit, i.e. k <= 256 (128) on a large store;
+ * beyond that VS_E_CAPACITY. Every call on one
  * GPU shares the array: calls whose kernels can overlap on that GPU (different
  * streams, or several threads) race; issue them on one stream. The call records
  * no event either (the stream may be under capture), so unlike the other

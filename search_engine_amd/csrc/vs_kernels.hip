@@ -1458,20 +1458,49 @@ __global__ __launch_bounds__(256) void roaring_expand_kernel(const uint8_t* byte
 
 // ---- launchers ------------------------------------------------------------------------
 
-// Default grid, measured on 10M x 768 f32 rows: an unfiltered scan is fastest
-// with one workgroup per CU (one wave per SIMD, 4 rows = 12 KiB in flight per
-// wave); with a candidate mask two workgroups per CU win, because one wave's
-// mask decoding then overlaps another's row loads. More waves lose bandwidth.
-uint32_t scan_grid_blocks(const SlabView& s, const ScanTuning& t, bool masked) {
+// Default grid of the scans that share passes between queries (scan_multi_kernel, scan_mq32_kernel)
+// and of the Hamming scan, measured on 10M x 768 f32 rows and 50M x 1536-bit rows: an unfiltered
+// scan is fastest with one workgroup per CU (one wave per SIMD); with a candidate mask two
+// workgroups per CU win, because one wave's mask decoding then overlaps another's row loads.
+static uint32_t shared_grid_blocks(const SlabView& s, const ScanTuning& t, bool masked) {
     if (t.blocks > 0) return (uint32_t)t.blocks;
     const uint64_t want = (s.n_slots + 1023) / 1024;  // >= 256 slots per wave
     const uint64_t cap = masked ? 2 * NUM_CUS : NUM_CUS;
     return (uint32_t)(want < 1 ? 1 : want > cap ? cap : want);
 }
 
+// Whether ONE wave per SIMD can keep HBM busy with the single-query float scan over rows of this
+// shape. A row costs its loads plus a fixed tail (reduction, distance, list test), so short rows
+// and bf16 rows (two conversions per pair of elements) are more instructions per byte, and one wave
+// then waits on its own arithmetic. Measured dense, one against two waves per SIMD, TB/s:
+// 3 KiB rows 7.19 / 7.00 (768 f32) and 7.09 / 6.94 (1536 bf16); 2 KiB 7.29 / 6.87 (512 f32) but
+// 6.63 / 6.87 (1024 bf16); 1.5 KiB 5.79 / 6.90 (384 f32) and 5.15 / 6.83 (768 bf16).
+static bool float_rows_stream_with_one_wave(const SlabView& s) {
+    return s.row_vecs >= 192 || (s.dtype == VS_F32 && s.row_vecs >= 128);
+}
+
+// Default grid of a single-query scan. Float rows that one wave per SIMD streams at full rate
+// take the grid above (and pair their workgroups under a mask, see scan_float_rows); other float
+// rows take two workgroups per CU with or without a mask, and four from 1 KiB per row down
+// (768-byte rows: 2.7 / 4.9 / 6.4 / 5.8 TB/s with 1 / 2 / 4 / 8 workgroups per CU, 512-byte rows
+// 2.0 / 3.7 / 5.4 / 5.5; the same order under a 10 % filter).
+uint32_t scan_grid_blocks(const SlabView& s, const ScanTuning& t, bool masked) {
+    if (t.blocks > 0) return (uint32_t)t.blocks;
+    if ((s.dtype != VS_F32 && s.dtype != VS_BF16) || float_rows_stream_with_one_wave(s))
+        return shared_grid_blocks(s, t, masked);
+    const uint64_t want = (s.n_slots + 1023) / 1024;  // >= 256 slots per wave
+    const uint64_t cap = (s.row_vecs <= 64 ? 4 : 2) * NUM_CUS;
+    return (uint32_t)(want < 1 ? 1 : want > cap ? cap : want);
+}
+
 uint64_t scan_partial_bytes(const SlabView& s, uint32_t k, const ScanTuning& t) {
-    const uint32_t a = scan_grid_blocks(s, t, true), b = scan_grid_blocks(s, t, false);
-    return (uint64_t)(a > b ? a : b) * k * sizeof(uint64_t);
+    uint32_t m = 0;
+    for (int masked = 0; masked < 2; ++masked) {
+        const uint32_t a = scan_grid_blocks(s, t, masked != 0), b = shared_grid_blocks(s, t, masked != 0);
+        m = a > m ? a : m;
+        m = b > m ? b : m;
+    }
+    return (uint64_t)m * k * sizeof(uint64_t);
 }
 
 uint64_t scan_workspace_bytes(const SlabView& s, uint32_t k) {
@@ -1539,7 +1568,9 @@ hipError_t launch_scan_float(const SlabView& s, const float* d_query, const uint
     if (s.metric == VS_ANGULAR && !s.norms) return hipErrorInvalidValue;
     const uint32_t blocks = scan_grid_blocks(s, t, cand != nullptr);
     // the default grid under a filter is two workgroups per CU: let them pair up (see scan_float_rows)
-    a.pair = (cand != nullptr && t.blocks <= 0 && blocks >= 2 && !(blocks & 1)) ? 1u : 0u;
+    a.pair = (cand != nullptr && t.blocks <= 0 && blocks >= 2 && !(blocks & 1) && float_rows_stream_with_one_wave(s))
+                 ? 1u
+                 : 0u;
     const size_t lds = (size_t)WAVES * k * 8 + (size_t)WAVES * QCAP * 4;
     hipError_t e;
     if (s.dtype == VS_F32)
@@ -1655,7 +1686,7 @@ hipError_t launch_scan_multi(const SlabView& s, const float* d_queries, uint32_t
         return hipErrorInvalidValue;
     const bool eight = n_q > 4;  // a group of up to four runs the lighter kernel
     const uint32_t lists = eight ? 8 : 4;
-    const uint32_t blocks = scan_grid_blocks(s, t, cand != nullptr);
+    const uint32_t blocks = shared_grid_blocks(s, t, cand != nullptr);
     MultiArgs m;
     m.s.rows = reinterpret_cast<const u32x4*>(s.rows);
     m.s.norms = s.norms;
@@ -1778,7 +1809,7 @@ hipError_t launch_scan_hamming_multi(const SlabView& s, const void* d_queries, u
     if (!scan_hamming_multi_serves(s, k) || n_q == 0 || n_q > (uint32_t)HQ || (s.n_slots & 63) ||
         s.n_slots == 0)
         return hipErrorInvalidValue;
-    const uint32_t blocks = scan_grid_blocks(s, t, cand != nullptr);
+    const uint32_t blocks = shared_grid_blocks(s, t, cand != nullptr);
     HammingMultiArgs m;
     m.s.rows = reinterpret_cast<const u32x4*>(s.rows);
     m.s.present = s.present;
