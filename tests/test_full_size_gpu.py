@@ -95,6 +95,46 @@ def test_config2_1m_x_768_f32_against_the_cpu_oracle(gpu_ctx, k):
         store.destroy()
 
 
+@pytest.mark.parametrize("dtype_name,dim,n", [
+    ("f32", 128, 1_100_000),   # 512-byte rows: four workgroups per CU
+    ("bf16", 384, 1_100_000),  # 768-byte rows: likewise
+    ("f32", 384, 600_000),     # 1.5 KiB rows: two per CU, with and without a mask
+    ("bf16", 768, 600_000),    # BASELINE's bf16 row shape: likewise
+])
+def test_short_rows_on_their_larger_default_grids(gpu_ctx, dtype_name, dim, n):
+    """The single-query scan sizes its default grid by the row shape (short and bf16 rows take two
+    or four workgroups per CU instead of one); stores this large reach those grids. Against the C
+    oracle, unfiltered and under 50 / 1 % facet filters, k = 10 and k = 100."""
+    from conftest import facet_mask
+    from oracle import scan as oracle
+    from search_engine_amd import abi
+    rng = np.random.default_rng(77 + dim)
+    vectors = rng.standard_normal((n, dim), dtype=np.float32)
+    if dtype_name == "bf16":
+        vectors = oracle.bf16_round(vectors)
+    queries = rng.standard_normal((2, dim), dtype=np.float32)
+    docids = np.arange(n, dtype=np.uint32)
+    store = gpu_ctx.create_store(0x7100 + dim + (1 if dtype_name == "bf16" else 0), dim, n,
+                                 dtype=abi.VS_BF16 if dtype_name == "bf16" else abi.VS_F32)
+    try:
+        for lo in range(0, n, 1 << 17):
+            store.upload(docids[lo:lo + (1 << 17)], vectors[lo:lo + (1 << 17)])
+        store.seal()
+        norms = oracle.norms(vectors)
+        for pass_percent, k in ((100, 10), (50, 100), (1, 10)):
+            mask = facet_mask(n, pass_percent) if pass_percent < 100 else None
+            n_cand = n if mask is None else int(oracle.mask_to_bool(mask, n).sum())
+            o_ids, _, o_n, _ = oracle.nns_batch_mt(vectors, queries, k, mask=mask, norms=norms)
+            for j, q in enumerate(queries):
+                ids, dist = store.search(q, k, mask)
+                assert o_n[j] == k
+                cand = sorted(set(ids.tolist()) | set(o_ids[j].tolist()))
+                d64 = dict(zip(cand, oracle.all_distances_f64(vectors[cand], q).tolist()))
+                assert check_hits(ids, dist, o_ids[j], d64, k, n_cand) <= 2
+    finally:
+        store.destroy()
+
+
 @pytest.mark.parametrize("pass_percent", [100, 10])
 def test_headline_10m_x_768_f32(gpu_ctx, pass_percent):
     from search_engine_amd import abi
