@@ -202,6 +202,45 @@ __device__ __forceinline__ void scan_masked_slots(const uint64_t* __restrict__ p
     if (qcount) score(0, qcount);
 }
 
+// Two waves per SIMD (twice as many workgroups as CUs) win under a selective filter, where one
+// wave's mask decoding overlaps the other's row loads; one wave per SIMD wins when most rows
+// pass (fewer, longer streams: 7.19 against 7.00 TB/s on 10 M x 768 f32 at 100 %, 6.9 against 6.8
+// at 50 %; 3.7 against 4.2 at 1 %). A launch does not know its filter's density, so in a paired
+// launch wave i of workgroup b and wave i of workgroup b + gridDim.x / 2 look at the same sample --
+// the first 64 mask words the two own together -- and take the same decision: dense (at least
+// `num` candidates in `den` slots), and the first wave takes all their words while the second has
+// nothing to do; sparse, and they split them as two independent waves would. Returns whether
+// this wave is the idle one; otherwise *w / *W are the wave's stride over the mask words and
+// *first_batch its first 64 words (one per lane, present & candidates).
+__device__ __forceinline__ bool pair_up_waves(const uint64_t* __restrict__ present,
+                                              const uint64_t* __restrict__ cand, uint64_t n_slots, int lane,
+                                              uint32_t wib, uint32_t num, uint32_t den, uint32_t* w, uint32_t* W,
+                                              uint64_t* first_batch) {
+    const uint32_t half = gridDim.x >> 1, hi = blockIdx.x >= half ? 1u : 0u;
+    const uint32_t Wp = half * WAVES, wp = (blockIdx.x - hi * half) * WAVES + wib;
+    const uint64_t n_words = n_slots >> 6;
+    auto word_at = [&](uint64_t wi) -> uint64_t {
+        if (wi >= n_words) return 0;
+        uint64_t x = present[wi];
+        if (cand) x &= cand[wi];
+        return x;
+    };
+    const uint64_t shared_words = word_at((uint64_t)wp + (uint64_t)lane * Wp);  // the pair's first 64
+    const uint64_t own_words = word_at((uint64_t)*w + (uint64_t)lane * *W);     // this wave's first 64 if they split
+    const uint64_t sampled = wp < n_words ? (n_words - wp + Wp - 1) / Wp : 0;
+    const float bits = wave_sum_f32((float)__popcll(shared_words));             // <= 4096: exact
+    const float slots = 64.0f * (float)(sampled < 64 ? sampled : 64);
+    if (bits * (float)den >= slots * (float)num) {
+        if (hi) return true;
+        *w = wp;
+        *W = Wp;
+        *first_batch = shared_words;
+    } else {
+        *first_batch = own_words;
+    }
+    return false;
+}
+
 // Workgroup epilogue: wave 0 absorbs the other waves' lists and writes the
 // workgroup's k best, rank-major, to partial[rank * gridDim.x + blockIdx.x].
 __device__ __forceinline__ void finish_block(WaveTopK& top, unsigned char* smem, int k, uint32_t wib,
@@ -240,42 +279,10 @@ __device__ __forceinline__ void scan_float_rows(const ScanArgs& a, unsigned char
     WaveTopK top;
     top.init(reinterpret_cast<uint64_t*>(smem) + (size_t)wib * k, k, lane);
 
-    // Two waves per SIMD (twice as many workgroups as CUs) win under a selective filter, where one
-    // wave's mask decoding overlaps the other's row loads; one wave per SIMD wins when most rows
-    // pass (fewer, longer streams: 7.19 against 7.00 TB/s on 10 M x 768 f32 at 100 %, 6.9 against 6.8
-    // at 50 %; 3.7 against 4.2 at 1 %). A launch does not know its filter's density, so with `pair`
-    // set wave i of workgroup b and wave i of workgroup b + gridDim.x / 2 look at the same sample --
-    // the first 64 mask words the two own together -- and take the same decision: dense (one
-    // candidate in six or more), and the first wave takes all their words while the second has
-    // nothing to do; sparse, and they split them as two independent waves would.
     bool idle = false, have_first = false;
     uint64_t first_batch = 0;
     if (a.pair) {
-        const uint32_t half = gridDim.x >> 1, hi = blockIdx.x >= half ? 1u : 0u;
-        const uint32_t Wp = half * WAVES, wp = (blockIdx.x - hi * half) * WAVES + wib;
-        const uint64_t n_words = a.n_slots >> 6;
-        auto word_at = [&](uint64_t wi) -> uint64_t {
-            if (wi >= n_words) return 0;
-            uint64_t x = a.present[wi];
-            if (a.cand) x &= a.cand[wi];
-            return x;
-        };
-        const uint64_t shared_words = word_at((uint64_t)wp + (uint64_t)lane * Wp);  // the pair's first 64
-        const uint64_t own_words = word_at((uint64_t)w + (uint64_t)lane * W);       // this wave's first 64 if they split
-        const uint64_t sampled = wp < n_words ? (n_words - wp + Wp - 1) / Wp : 0;
-        const float bits = wave_sum_f32((float)__popcll(shared_words));           // <= 4096: exact
-        const float slots = 64.0f * (float)(sampled < 64 ? sampled : 64);
-        if (bits * 6.0f >= slots) {
-            if (hi) {
-                idle = true;
-            } else {
-                w = wp;
-                W = Wp;
-                first_batch = shared_words;
-            }
-        } else {
-            first_batch = own_words;
-        }
+        idle = pair_up_waves(a.present, a.cand, a.n_slots, lane, wib, 1, 6, &w, &W, &first_batch);
         have_first = true;
     }
 
@@ -959,6 +966,7 @@ struct HammingArgs {
     uint32_t docid_base;
     uint32_t k;
     uint32_t park = 0;  // non-zero: candidates are parked and merged in batches (WaveTopK::park)
+    uint32_t pair = 0;  // non-zero: workgroups b and b + gridDim.x / 2 share their mask words (pair_up_waves)
 };
 
 // Dense stretches of 192-byte rows. A row is one and a half 128-byte lines, so the quad
@@ -1034,13 +1042,21 @@ __global__ __launch_bounds__(WAVES * 64) void scan_hamming_kernel(HammingArgs a)
     const int lane = threadIdx.x & 63;
     const int quad = lane >> 2, sub = lane & 3;
     const uint32_t wib = uniform_u32(threadIdx.x >> 6);
-    const uint32_t W = gridDim.x * WAVES;
-    const uint32_t w = blockIdx.x * WAVES + wib;
+    uint32_t W = gridDim.x * WAVES;
+    uint32_t w = blockIdx.x * WAVES + wib;
     const int k = (int)a.k;
     uint32_t* queue =
         reinterpret_cast<uint32_t*>(smem + (size_t)WAVES * k * 8) + (size_t)wib * QCAP;
     WaveTopK top;
     top.init(reinterpret_cast<uint64_t*>(smem) + (size_t)wib * k, k, lane);
+    // paired launch: where nearly every slot is a candidate (the whole-word path below) one wave per
+    // SIMD streams faster (50 M x 1536 bit, all-ones mask: 6.94 against 6.78 TB/s)
+    bool idle = false, have_first = false;
+    uint64_t first_batch = 0;
+    if (a.pair) {
+        idle = pair_up_waves(a.present, a.cand, a.n_slots, lane, wib, 7, 8, &w, &W, &first_batch);
+        have_first = true;
+    }
     if (a.park)  // (the launcher adds the buffers behind the queues)
         top.park_in(reinterpret_cast<uint64_t*>(smem + (size_t)WAVES * k * 8 + (size_t)WAVES * QCAP * 4) + (size_t)wib * 128);
 
@@ -1102,13 +1118,17 @@ __global__ __launch_bounds__(WAVES * 64) void scan_hamming_kernel(HammingArgs a)
         if (a.row_vecs == 12) {  // 1536-bit rows: whole words of candidates go through the pair path
             HammingPairs<NT> pairs{a.rows, a.docid_base, lane, &top};
             pairs.load_query(a.query);
-            scan_masked_slots<16 * U>(a.present, a.cand, a.n_slots, w, W, lane, queue, score_rows, pairs);
+            if (!idle)
+                scan_masked_slots<16 * U>(a.present, a.cand, a.n_slots, w, W, lane, queue, score_rows, pairs,
+                                          EveryWord(), have_first, first_batch);
             top.merge_parked();
             finish_block(top, smem, k, wib, lane, a.partial);
             return;
         }
     }
-    scan_masked_slots<16 * U>(a.present, a.cand, a.n_slots, w, W, lane, queue, score_rows);
+    if (!idle)
+        scan_masked_slots<16 * U>(a.present, a.cand, a.n_slots, w, W, lane, queue, score_rows, NoDenseFn(),
+                                  EveryWord(), have_first, first_batch);
     top.merge_parked();
     finish_block(top, smem, k, wib, lane, a.partial);
 }
@@ -1615,6 +1635,9 @@ hipError_t launch_scan_hamming(const SlabView& s, const void* d_query, const uin
     // top-100 under a filter: an insert at a time was 30 to 40 us of every launch (50 M x 1536 bit)
     a.park = (k > 32 && k <= (uint32_t)WaveTopK::REG_K) ? 1u : 0u;
     const uint32_t blocks = scan_grid_blocks(s, t, cand != nullptr);
+    // the default grid under a filter is two workgroups per CU: let them pair up where the rows
+    // have the whole-word path (1536 bits)
+    a.pair = (cand != nullptr && t.blocks <= 0 && blocks >= 2 && !(blocks & 1) && s.row_vecs == 12) ? 1u : 0u;
     const size_t lds = (size_t)WAVES * k * 8 + (size_t)WAVES * QCAP * 4 + (a.park ? (size_t)WAVES * 128 * 8 : 0);
     const uint32_t ni = (s.row_vecs + 3) / 4;
     hipError_t e;
