@@ -1478,15 +1478,24 @@ __global__ __launch_bounds__(256) void roaring_expand_kernel(const uint8_t* byte
 
 // ---- launchers ------------------------------------------------------------------------
 
-// Default grid of the scans that share passes between queries (scan_multi_kernel, scan_mq32_kernel)
-// and of the Hamming scan, measured on 10M x 768 f32 rows and 50M x 1536-bit rows: an unfiltered
-// scan is fastest with one workgroup per CU (one wave per SIMD); with a candidate mask two
-// workgroups per CU win, because one wave's mask decoding then overlaps another's row loads.
-static uint32_t shared_grid_blocks(const SlabView& s, const ScanTuning& t, bool masked) {
+// Default grid of the Hamming scan (and of the float scan over rows that one wave per SIMD streams
+// at full rate, below), measured on 50M x 1536-bit and 10M x 768 f32 rows: an unfiltered scan is
+// fastest with one workgroup per CU (one wave per SIMD); with a candidate mask two workgroups per
+// CU win, because one wave's mask decoding then overlaps another's row loads.
+static uint32_t light_grid_blocks(const SlabView& s, const ScanTuning& t, bool masked) {
     if (t.blocks > 0) return (uint32_t)t.blocks;
     const uint64_t want = (s.n_slots + 1023) / 1024;  // >= 256 slots per wave
     const uint64_t cap = masked ? 2 * NUM_CUS : NUM_CUS;
     return (uint32_t)(want < 1 ? 1 : want > cap ? cap : want);
+}
+
+// Default grid of the scans in which several queries share a pass (scan_multi_kernel,
+// scan_hamming_multi_kernel): every row costs four or eight queries' arithmetic, so one wave per
+// SIMD waits on itself; two workgroups per CU with or without a mask (10M x 768 f32, eight queries
+// per pass: 6.17 ms with 256 workgroups, 4.84 with 512, 4.91 with 1024; 384-d f32 5.40 / 3.56 /
+// 3.68; 768-d bf16, four per pass, 5.09 / 3.37 / 3.47).
+static uint32_t shared_grid_blocks(const SlabView& s, const ScanTuning& t, bool masked) {
+    return light_grid_blocks(s, t, true);
 }
 
 // Whether ONE wave per SIMD can keep HBM busy with the single-query float scan over rows of this
@@ -1507,7 +1516,7 @@ static bool float_rows_stream_with_one_wave(const SlabView& s) {
 uint32_t scan_grid_blocks(const SlabView& s, const ScanTuning& t, bool masked) {
     if (t.blocks > 0) return (uint32_t)t.blocks;
     if ((s.dtype != VS_F32 && s.dtype != VS_BF16) || float_rows_stream_with_one_wave(s))
-        return shared_grid_blocks(s, t, masked);
+        return light_grid_blocks(s, t, masked);
     const uint64_t want = (s.n_slots + 1023) / 1024;  // >= 256 slots per wave
     const uint64_t cap = (s.row_vecs <= 64 ? 4 : 2) * NUM_CUS;
     return (uint32_t)(want < 1 ? 1 : want > cap ? cap : want);

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--metric", default="angular")
     ap.add_argument("--queries", type=int, default=64)
     ap.add_argument("--pass-percents", default="100,10,1")
+    ap.add_argument("--unmasked", action="store_true", help="pass no mask at all (pass rate 100 only)")
     ap.add_argument("--no-check", action="store_true", help="skip the comparison with vs_search (ablated builds)")
     args = ap.parse_args()
     from search_engine_amd import abi
@@ -54,7 +55,7 @@ def main():
         dmask = device_mask(torch, 0, n, p, dev)
         n_pass = int(lut[dmask.view(torch.uint8).long()].sum().item())
         algo = n_pass * (store.row_bytes + (4 if metric == abi.VS_ANGULAR else 0)) + n // 8
-        mask = dmask.cpu().numpy().view(np.uint64)
+        mask = None if args.unmasked and p == 100 else dmask.cpu().numpy().view(np.uint64)
         store.search_batch(queries, args.k, mask)
         t0 = time.perf_counter()
         reps = 3
