@@ -1494,7 +1494,7 @@ static uint32_t light_grid_blocks(const SlabView& s, const ScanTuning& t, bool m
 // SIMD waits on itself; two workgroups per CU with or without a mask (10M x 768 f32, eight queries
 // per pass: 6.17 ms with 256 workgroups, 4.84 with 512, 4.91 with 1024; 384-d f32 5.40 / 3.56 /
 // 3.68; 768-d bf16, four per pass, 5.09 / 3.37 / 3.47).
-static uint32_t shared_grid_blocks(const SlabView& s, const ScanTuning& t, bool masked) {
+static uint32_t shared_grid_blocks(const SlabView& s, const ScanTuning& t) {
     return light_grid_blocks(s, t, true);
 }
 
@@ -1525,7 +1525,7 @@ uint32_t scan_grid_blocks(const SlabView& s, const ScanTuning& t, bool masked) {
 uint64_t scan_partial_bytes(const SlabView& s, uint32_t k, const ScanTuning& t) {
     uint32_t m = 0;
     for (int masked = 0; masked < 2; ++masked) {
-        const uint32_t a = scan_grid_blocks(s, t, masked != 0), b = shared_grid_blocks(s, t, masked != 0);
+        const uint32_t a = scan_grid_blocks(s, t, masked != 0), b = shared_grid_blocks(s, t);
         m = a > m ? a : m;
         m = b > m ? b : m;
     }
@@ -1718,7 +1718,7 @@ hipError_t launch_scan_multi(const SlabView& s, const float* d_queries, uint32_t
         return hipErrorInvalidValue;
     const bool eight = n_q > 4;  // a group of up to four runs the lighter kernel
     const uint32_t lists = eight ? 8 : 4;
-    const uint32_t blocks = shared_grid_blocks(s, t, cand != nullptr);
+    const uint32_t blocks = shared_grid_blocks(s, t);
     MultiArgs m;
     m.s.rows = reinterpret_cast<const u32x4*>(s.rows);
     m.s.norms = s.norms;
@@ -1841,7 +1841,7 @@ hipError_t launch_scan_hamming_multi(const SlabView& s, const void* d_queries, u
     if (!scan_hamming_multi_serves(s, k) || n_q == 0 || n_q > (uint32_t)HQ || (s.n_slots & 63) ||
         s.n_slots == 0)
         return hipErrorInvalidValue;
-    const uint32_t blocks = shared_grid_blocks(s, t, cand != nullptr);
+    const uint32_t blocks = shared_grid_blocks(s, t);
     HammingMultiArgs m;
     m.s.rows = reinterpret_cast<const u32x4*>(s.rows);
     m.s.present = s.present;
