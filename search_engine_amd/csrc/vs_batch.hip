@@ -645,8 +645,15 @@ struct Int {
 typedef const __attribute__((address_space(4))) uint32_t* const_u32;
 typedef const __attribute__((address_space(4))) uint64_t* const_u64;
 
-template <bool GATHER>
+// NARROW: a batch of 128 queries or fewer. The image and the loads keep their 256-row shape, but
+// all eight waves work on the first 128 query columns -- 64 per wave, half the matrix instructions
+// and half the query fragments -- and nobody fetches query rows 128 .. 255. (With the full-width
+// mapping waves s and s + 4, which share SIMD s, own the same 128 columns: absent queries would
+// leave two SIMDs in four multiplying zeros while the other two carry the tile.)
+template <bool GATHER, bool NARROW>
 __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs a) {
+    constexpr uint32_t QW = NARROW ? 64 : 128;  // query columns per wave
+    constexpr int NQ16 = QW / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     typedef __attribute__((address_space(3))) void* lds_ptr;
     const uint32_t tid = threadIdx.x;
@@ -667,8 +674,8 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
     bool bad = false;
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
-        const uint32_t q = wn * 128 + (uint32_t)n * 16 + r16;
-        col_ok[n] = q < a.n_q;
+        const uint32_t q = wn * QW + (uint32_t)n * 16 + r16;
+        col_ok[n] = n < NQ16 && q < a.n_q;
         c2v[n] = 3.0e38f;
         if (col_ok[n]) {
             const uint64_t tau = a.bound_keys[(uint64_t)q * k + (k - 1)];
@@ -766,6 +773,11 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
                                                          (int)(ks * 128u + (wv * 4 + i) * 8u * row_bytes), 0, 2);
         } else {
             const int i = pc - 4;
+            if (NARROW && wv >= 4) return;  // query rows 128 .. 255: nobody reads them
+            // eight query rows the batch does not hold: their columns' scores are never looked at
+            // (col_ok), so whatever the image holds there may be multiplied
+            // (narrow build only: in the full-width one the branches cost more than the pieces)
+            if (NARROW && (wv * 4 + (uint32_t)i) * 8u >= a.n_q) return;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(qres, (lds_ptr)(img + IMG_B + i * 1024), 16, (int)dvb[i & 1],
                                                      (int)(ks * 128u + (wv * 4 + i) * 8u * (KS * 128u)), 0, 0);
         }
@@ -807,7 +819,7 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
     uint32_t image = 0;  // the image the step about to be multiplied lies in
     load_step(t0, s0, 0, image);
 
-    const uint32_t frag_a = swz(wm * 64 + r16, quarter), frag_b = IMG_B + swz(wn * 128 + r16, quarter);
+    const uint32_t frag_a = swz(wm * 64 + r16, quarter), frag_b = IMG_B + swz(wn * QW + r16, quarter);
     uint32_t t_prev = TILE_NONE;
 
     // The matrix instruction is v_mfma_f32_16x16x32_bf16: a 64-element step is two sub-steps of 32, a
@@ -837,6 +849,7 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
 #endif
     };
     auto read_b = [&](const unsigned char* img, int kk, int h, bf16x8 (&xb)[4]) {
+        if (NARROW && h == 1) return;
         uint32_t fo = frag_b ^ ((uint32_t)kk << 6);
         asm volatile("" : "+v"(fo));
 #pragma unroll
@@ -938,6 +951,7 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
             }
             auto multiply = [&](auto H, const bf16x8 (&xa)[4], const bf16x8 (&xb)[4]) {
                 constexpr int h = decltype(H)::value;
+                if (NARROW && h == 1) return;
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -1009,7 +1023,7 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
             for (int m = 0; m < 4; ++m) pn4[m] = *reinterpret_cast<const f32x4v*>(norm_mine + m * 16);
             float tmax[8];
 #pragma unroll
-            for (int n = 0; n < 8; ++n) {
+            for (int n = 0; n < NQ16; ++n) {
                 tmax[n] = -__builtin_inff();
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
@@ -1018,7 +1032,7 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
                         tmax[n] = __builtin_fmaxf(tmax[n], __builtin_fmaf(-pn4[m][e], c2v[n], acc[m][n][e]));
             }
 #pragma unroll
-            for (int n = 0; n < 8; ++n) {
+            for (int n = 0; n < NQ16; ++n) {
 #ifdef VS_ABL_NOHITS
                 const bool lane_hit = tmax[n] >= 3.0e38f;
 #else
@@ -1045,7 +1059,7 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
                     const uint32_t idx = lds_add_return(qcount + par, 1u);
                     if (idx < (uint32_t)QCAP)
                         queue[par * QCAP + idx] = ((uint64_t)__float_as_uint(v) << 32) |
-                                                  ((wn * 128 + (uint32_t)n * 16 + r16) << 8) | (wm * 64 + wrow);
+                                                  ((wn * QW + (uint32_t)n * 16 + r16) << 8) | (wm * 64 + wrow);
                 }
             }
         }
@@ -1638,7 +1652,8 @@ hipError_t launch_scan_batch_bf16(const SlabView& s, const float* d_queries, uin
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(gather_sample_keys_kernel, dim3((n_q * k + 255) / 256), dim3(256), 0, stream, sample, n_q * k, head);
         // the streaming pass over the rest of the list
-        void (*gather_kernel)(StreamArgs) = scan_batch_stream_kernel<true>;
+        void (*gather_kernel)(StreamArgs) =
+            n_q <= 128 ? scan_batch_stream_kernel<true, true> : scan_batch_stream_kernel<true, false>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(gather_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 S_LDS);
         if (e != hipSuccess) return e;
@@ -1715,7 +1730,8 @@ hipError_t launch_scan_batch_bf16(const SlabView& s, const float* d_queries, uin
     static const bool use_stream = getenv("VS_BATCH_NO_STREAM") == nullptr;  // measurement switch
     if (use_stream) {
         StreamArgs sa;
-        void (*stream_kernel)(StreamArgs) = scan_batch_stream_kernel<false>;
+        void (*stream_kernel)(StreamArgs) =
+            n_q <= 128 ? scan_batch_stream_kernel<false, true> : scan_batch_stream_kernel<false, false>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(stream_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS);
         if (e != hipSuccess) return e;

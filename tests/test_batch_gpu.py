@@ -88,13 +88,17 @@ def test_batch_parity_filters_and_holes(gpu_ctx, pass_percent):
         store.destroy()
 
 
+@pytest.mark.parametrize("n_q", [19, 100, 150])
 @pytest.mark.parametrize("dim", [100, 160])
-def test_streaming_pass_with_two_and_three_step_tiles(gpu_ctx, dim):
+def test_streaming_pass_with_two_and_three_step_tiles(gpu_ctx, dim, n_q):
     """The streaming second pass requests a step's rows two steps ahead, across tile boundaries: tiles
-    of two steps (100 dimensions) and of three (160), next to the one-step tiles of the test below."""
+    of two steps (100 dimensions) and of three (160), next to the one-step tiles of the test below.
+    Batches of up to 128 queries take the narrow build of that pass (64 query columns per wave; 100
+    queries reach into its second column group), larger ones the full-width build; three-step tiles
+    under the 40 % filter are fetched in place, so both builds of the gathered form run as well."""
     n = 256 * 256 * 2 + 64 * 5
     vectors = synthetic_vectors(n, dim, 0x51DE + dim)
-    queries = synthetic_vectors(19, dim, 0x51DF + dim)
+    queries = synthetic_vectors(n_q, dim, 0x51DF + dim)
     rng = np.random.default_rng(dim)
     for j in range(queries.shape[0]):
         for pos in rng.choice(n, 4, replace=False):
