@@ -1558,7 +1558,13 @@ static hipError_t launch_scan_e(const ScanArgs& a, uint32_t blocks, size_t lds, 
                                 hipStream_t stream) {
     const uint32_t nch = (a.row_vecs + 63) / 64;
     if (nch <= 1) return launch_scan_t<ELEM, 1, 8>(a, blocks, lds, t, stream);
-    if (nch <= 2) return launch_scan_t<ELEM, 2, 8>(a, blocks, lds, t, stream);
+    if (nch <= 2) {
+        if (a.metric == VS_ANGULAR) {  // schedule probes, angular only
+            if (t.rows_in_flight == 4) return launch_scan_t<ELEM, 2, 4>(a, blocks, lds, t, stream);
+            if (t.rows_in_flight == 16) return launch_scan_t<ELEM, 2, 16>(a, blocks, lds, t, stream);
+        }
+        return launch_scan_t<ELEM, 2, 8>(a, blocks, lds, t, stream);
+    }
     if (nch <= 3) {
         if (a.metric == VS_ANGULAR) {  // schedule probes, angular only
             if (t.rows_in_flight == 2) return launch_scan_t<ELEM, 3, 2>(a, blocks, lds, t, stream);

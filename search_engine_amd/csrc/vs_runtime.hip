@@ -528,7 +528,7 @@ extern "C" int32_t vs_init(int32_t device_ordinal, vs_ctx** out) {
     };
     env_int("VS_SCAN_BLOCKS", 0, vs::MAX_TUNED_BLOCKS, &ctx->tune_blocks);
     env_int("VS_SCAN_NT", 0, 1, &ctx->tune_nt);
-    env_int("VS_SCAN_ROWS", 0, 8, &ctx->tune_rows);
+    env_int("VS_SCAN_ROWS", 0, 16, &ctx->tune_rows);
     HIP_TRY(hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
     HIP_TRY(hipHostMalloc(&ctx->h_small, 64 << 10, hipHostMallocDefault));
     // device `device_ordinal` is current: this is its copy of the array
