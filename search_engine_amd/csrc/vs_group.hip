@@ -165,18 +165,15 @@ extern "C" int32_t vs_search_sharded_device(vs_group* g, vs_store* s, const void
                 HIP_TRY(vs::launch_merge_batch(g->d_local, 1, k, 1, n_q, k, k, v.metric, nullptr, d_out_ids,
                                                d_out_dist, d_out_n, stream));
         } else {
-            // one scan per query, each bit-identical to vs_search; the per-workgroup lists of all
-            // queries are merged by ONE launch
+            // ONE launch scans for every query in turn (no row read is shared: each list is bit-identical
+            // to vs_search's), ONE launch merges the per-workgroup lists of all queries
             const uint32_t blocks = vs::scan_grid_blocks(v, t, d_mask_words != nullptr);
             const size_t per_query = (size_t)blocks * k;
             if (int32_t rc = grow(&g->d_partial, &g->partial_bytes, per_query * 8 * n_q)) return rc;
             const size_t q_bytes = v.dtype == VS_BIN1 ? (size_t)v.row_vecs * 16 : (size_t)v.dim * 4;
-            const unsigned char* q = static_cast<const unsigned char*>(d_queries);
-            for (uint32_t i = 0; i < n_q; ++i)
-                if (int32_t rc = vsrt::launch_scan(v, t, q + i * q_bytes, d_mask_words, k,
-                                                   g->d_partial + i * per_query, nullptr, nullptr, nullptr, nullptr,
-                                                   stream))
-                    return rc;
+            if (int32_t rc = vsrt::launch_scan_queries(v, t, d_queries, q_bytes, n_q, d_mask_words, nullptr, k,
+                                                       g->d_partial, stream))
+                return rc;
             HIP_TRY(vs::launch_merge_batch(g->d_partial, blocks, 1, blocks, n_q, per_query, k, v.metric, local_keys,
                                            gather ? nullptr : d_out_ids, gather ? nullptr : d_out_dist,
                                            gather ? nullptr : d_out_n, stream));

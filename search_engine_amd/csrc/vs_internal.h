@@ -80,7 +80,7 @@ struct vs_ctx {
     std::map<uint16_t, vs_store*> stores;
     std::vector<std::unique_ptr<vsrt::Workspace>> pool;
     // scan schedule knobs; read as one snapshot per call (vsrt::tuning_of)
-    std::atomic<int32_t> tune_blocks{0}, tune_nt{1}, tune_rows{0};
+    std::atomic<int32_t> tune_blocks{0}, tune_nt{1}, tune_rows{0}, tune_qlanes{0};
     unsigned char* d_scratch = nullptr;  // this GPU's copy of the static scratch array (vs_search_device_noalloc)
     // writer side: upload staging (guarded by upload_mu; the engine has one writer)
     std::mutex upload_mu;
@@ -207,6 +207,11 @@ int32_t check_device_search(vs_store* s, uint32_t dim, uint32_t k);
 int32_t launch_scan(const vs::SlabView& v, const vs::ScanTuning& t, const void* d_query, const uint64_t* d_cand,
                     uint32_t k, uint64_t* d_partial, uint64_t* d_keys, uint32_t* d_ids, float* d_dist,
                     uint32_t* d_n, hipStream_t stream);
+// `n_q` independent single-query scans in one launch (partial lists only; the caller merges):
+// query q at d_queries + q * query_bytes, under d_cand_of[q] (device array, nullable) or d_cand.
+int32_t launch_scan_queries(const vs::SlabView& v, const vs::ScanTuning& t, const void* d_queries,
+                            size_t query_bytes, uint32_t n_q, const uint64_t* d_cand,
+                            const uint64_t* const* d_cand_of, uint32_t k, uint64_t* d_partial, hipStream_t stream);
 // The batched device search on an already registered snapshot (vs_search_batch_device's body).
 int32_t launch_batch(vs_store* s, const vs::SlabView& v, const vs::ScanTuning& t, const void* d_queries,
                      uint32_t n_q, uint32_t k, const uint64_t* d_mask_words, void* d_workspace,

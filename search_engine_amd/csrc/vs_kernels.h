@@ -30,6 +30,7 @@ struct ScanTuning {
     int32_t blocks;  // grid size, 0 = default
     int32_t nt;      // non-zero: non-temporal row loads (the default)
     int32_t rows_in_flight = 0;  // rows one wave loads before it scores them, 0 = default
+    int32_t query_lanes = 0;     // many-query launches: queries in flight per share of the mask words, 0 = default (1)
 };
 
 uint32_t scan_grid_blocks(const SlabView& s, const ScanTuning& t, bool masked);
@@ -52,6 +53,22 @@ hipError_t launch_scan_float(const SlabView& s, const float* d_query, const uint
                                uint32_t k, uint64_t* partial, uint64_t* out_keys,
                                uint32_t* out_ids, float* out_dist, uint32_t* out_n,
                                const ScanTuning& t, hipStream_t stream);
+
+// `n_q` independent single-query scans in ONE launch: a workgroup takes its share of the mask words
+// for one query after the other, so the queries follow each other without a launch's ramp and tail
+// in between. No row read is shared; query q's partial lists (at partial + q * blocks * k keys, blocks =
+// scan_grid_blocks(s, t, masked), rank-major as above) are bit for bit what launch_scan_float writes
+// for it alone. Query q starts at d_queries + q * query_stride floats and is searched under
+// d_cand_of[q] if `d_cand_of` (a device array of n_q device pointers, entries nullable) is given,
+// else under `cand` (nullable); masked = either is non-null. `partial` needs n_q times
+// scan_partial_bytes. The caller merges, e.g. all queries in one launch_merge_batch.
+hipError_t launch_scan_float_queries(const SlabView& s, const float* d_queries, uint32_t query_stride,
+                                     uint32_t n_q, const uint64_t* cand, const uint64_t* const* d_cand_of,
+                                     uint32_t k, uint64_t* partial, const ScanTuning& t, hipStream_t stream);
+// The same over a VS_BIN1 slab; query_stride in 16-byte vectors.
+hipError_t launch_scan_hamming_queries(const SlabView& s, const void* d_queries, uint32_t query_stride,
+                                       uint32_t n_q, const uint64_t* cand, const uint64_t* const* d_cand_of,
+                                       uint32_t k, uint64_t* partial, const ScanTuning& t, hipStream_t stream);
 
 // Up to scan_multi_queries(s) queries (eight for f32 rows of up to 768 dimensions, else four) in
 // one pass over the rows. Serves f32 rows of up to 1536 dimensions and bf16 rows of up to 1536,

@@ -43,6 +43,15 @@ struct ScanArgs {
     uint32_t k;
     int32_t metric;  // host-side dispatch only
     uint32_t pair = 0;  // non-zero: workgroups b and b + gridDim.x / 2 share their mask words (scan_float_rows)
+    // Several independent queries in one launch: workgroup (b, y) takes the b-th share of the mask
+    // words for the queries y, y + gridDim.y, ... one after the other, so that a workgroup which has
+    // finished its share of one query goes straight on to the next (no ramp and tail per query, one
+    // launch per step). No row read is shared: every list is what a launch of its own would write.
+    uint32_t n_q = 1;
+    uint32_t query_stride = 0;            // floats (Hamming: 16-byte vectors) between consecutive queries
+    uint64_t partial_stride = 0;          // keys between consecutive queries' partial lists
+    const uint64_t* const* cand_of = nullptr;  // nullable: one candidate mask per query (entries nullable) instead of `cand`
+    uint32_t list_bufs = 1;               // 2: the waves' LDS lists alternate between two buffers from query to query
 };
 
 __device__ __forceinline__ uint32_t lanes_below(uint64_t m) {
@@ -202,6 +211,18 @@ __device__ __forceinline__ void scan_masked_slots(const uint64_t* __restrict__ p
     if (qcount) score(0, qcount);
 }
 
+// The first 64 mask words of wave `w` of `W` (present & candidates), one per lane: what
+// scan_masked_slots fetches first, for callers that want to look at them before.
+__device__ __forceinline__ uint64_t first_mask_words(const uint64_t* __restrict__ present,
+                                                     const uint64_t* __restrict__ cand, uint64_t n_slots,
+                                                     uint32_t w, uint32_t W, int lane) {
+    const uint64_t wi = (uint64_t)w + (uint64_t)lane * W;
+    if (wi >= (n_slots >> 6)) return 0;
+    uint64_t x = present[wi];
+    if (cand) x &= cand[wi];
+    return x;
+}
+
 // Two waves per SIMD (twice as many workgroups as CUs) win under a selective filter, where one
 // wave's mask decoding overlaps the other's row loads; one wave per SIMD wins when most rows
 // pass (fewer, longer streams: 7.19 against 7.00 TB/s on 10 M x 768 f32 at 100 %, 6.9 against 6.8
@@ -215,7 +236,7 @@ __device__ __forceinline__ void scan_masked_slots(const uint64_t* __restrict__ p
 __device__ __forceinline__ bool pair_up_waves(const uint64_t* __restrict__ present,
                                               const uint64_t* __restrict__ cand, uint64_t n_slots, int lane,
                                               uint32_t wib, uint32_t num, uint32_t den, uint32_t* w, uint32_t* W,
-                                              uint64_t* first_batch) {
+                                              uint64_t* first_batch, bool* dense = nullptr) {
     const uint32_t half = gridDim.x >> 1, hi = blockIdx.x >= half ? 1u : 0u;
     const uint32_t Wp = half * WAVES, wp = (blockIdx.x - hi * half) * WAVES + wib;
     const uint64_t n_words = n_slots >> 6;
@@ -230,7 +251,9 @@ __device__ __forceinline__ bool pair_up_waves(const uint64_t* __restrict__ prese
     const uint64_t sampled = wp < n_words ? (n_words - wp + Wp - 1) / Wp : 0;
     const float bits = wave_sum_f32((float)__popcll(shared_words));             // <= 4096: exact
     const float slots = 64.0f * (float)(sampled < 64 ? sampled : 64);
-    if (bits * (float)den >= slots * (float)num) {
+    const bool is_dense = bits * (float)den >= slots * (float)num;
+    if (dense) *dense = is_dense;
+    if (is_dense) {
         if (hi) return true;
         *w = wp;
         *W = Wp;
@@ -239,6 +262,35 @@ __device__ __forceinline__ bool pair_up_waves(const uint64_t* __restrict__ prese
         *first_batch = own_words;
     }
     return false;
+}
+
+// Query lanes of a many-query launch. gridDim.y workgroups share each share of the mask words and
+// split the launch's queries between them (lane y takes y, y + gridDim.y, ...): under a selective
+// filter a wave spends most of a query waiting for a handful of scattered rows, and several queries in
+// flight per SIMD hide that (1 M x 768 f32 at 1 %: 11.1 us per query with one lane, 7.1 with four).
+// A dense scan wants the opposite, one streaming wave per SIMD (10 M x 768 f32 at 100 %: 0.899 of the
+// HBM peak with one lane, 0.876 with four). Every workgroup of a share looks at the same sample of
+// the mask, so they agree without talking: where all four waves see a dense sample, lane 0 takes
+// every query and the other lanes leave. Sets the first query and the stride of this workgroup's
+// loop; returns false if it has nothing to do.
+__device__ __forceinline__ bool split_queries(bool dense_here, uint32_t* y0, uint32_t* y_step) {
+    *y0 = blockIdx.y;
+    *y_step = gridDim.y;
+    if (gridDim.y == 1) return true;
+    if (__syncthreads_and(dense_here ? 1 : 0)) {
+        if (blockIdx.y != 0) return false;
+        *y_step = 1;
+    }
+    return true;
+}
+// Whether at least `num` in `den` of the slots of a wave's first 64 mask words are candidates.
+__device__ __forceinline__ bool sample_is_dense(uint64_t first_batch, uint64_t n_slots, uint32_t w, uint32_t W,
+                                                uint32_t num, uint32_t den) {
+    const uint64_t n_words = n_slots >> 6;
+    const uint64_t mine = w < n_words ? (n_words - w + W - 1) / W : 0;
+    const float bits = wave_sum_f32((float)__popcll(first_batch));
+    const float slots = 64.0f * (float)(mine < 64 ? mine : 64);
+    return bits * (float)den >= slots * (float)num;
 }
 
 // Workgroup epilogue: wave 0 absorbs the other waves' lists and writes the
@@ -270,81 +322,108 @@ __device__ __forceinline__ void scan_float_rows(const ScanArgs& a, unsigned char
     constexpr int EPV = Epv<ELEM>::value;
     const int lane = threadIdx.x & 63;
     const uint32_t wib = uniform_u32(threadIdx.x >> 6);
-    uint32_t W = gridDim.x * WAVES;
-    uint32_t w = blockIdx.x * WAVES + wib;
+    const uint32_t W0 = gridDim.x * WAVES, w0 = blockIdx.x * WAVES + wib;
     const int k = (int)a.k;
+    const size_t list_bytes = (size_t)WAVES * k * 8;
 
-    uint32_t* queue =
-        reinterpret_cast<uint32_t*>(smem + (size_t)WAVES * k * 8) + (size_t)wib * QCAP;
-    WaveTopK top;
-    top.init(reinterpret_cast<uint64_t*>(smem) + (size_t)wib * k, k, lane);
+    uint32_t* queue = reinterpret_cast<uint32_t*>(smem + a.list_bufs * list_bytes) + (size_t)wib * QCAP;
 
+    // What a wave takes of the mask words depends on the mask alone: decided once when every query
+    // of the launch is searched under the same one.
+    uint32_t W = W0, w = w0;
     bool idle = false, have_first = false;
     uint64_t first_batch = 0;
-    if (a.pair) {
-        idle = pair_up_waves(a.present, a.cand, a.n_slots, lane, wib, 1, 6, &w, &W, &first_batch);
+    bool dense = a.cand == nullptr;
+    if (a.pair && !a.cand_of) {
+        idle = pair_up_waves(a.present, a.cand, a.n_slots, lane, wib, 1, 6, &w, &W, &first_batch, &dense);
         have_first = true;
+    } else if (gridDim.y > 1 && a.cand && !a.cand_of) {
+        first_batch = first_mask_words(a.present, a.cand, a.n_slots, w, W, lane);
+        have_first = true;
+        dense = sample_is_dense(first_batch, a.n_slots, w, W, 1, 6);
     }
+    uint32_t y0, y_step;
+    if (!split_queries(dense && !a.cand_of, &y0, &y_step)) return;
 
-    // this lane's slice of the query, and ‖q‖ summed in the row order
-    float q[NCH][EPV];
-    float qq = 0.0f;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-#pragma unroll
-        for (int j = 0; j < EPV; ++j) {
-            const uint32_t e = (uint32_t)(c * 64 + lane) * EPV + j;
-            q[c][j] = e < a.dim ? a.query[e] : 0.0f;
-            qq = __builtin_fmaf(q[c][j], q[c][j], qq);
-        }
-    }
-    const float qn = sqrtf(wave_sum_f32(qq));
-    wave_lds_fence();
-
-    // Scores rows queue[head .. head+U); the first `nvalid` of them count.
-    auto score_rows = [&](uint32_t head, uint32_t nvalid) {
-        uint32_t slot[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t at = head + ((uint32_t)u < nvalid ? (uint32_t)u : nvalid - 1);
-            slot[u] = uniform_u32(queue[at]);
-        }
-        u32x4 x[U][NCH];
-        float pn[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const u32x4* rp = a.rows + (uint64_t)slot[u] * a.row_vecs;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const uint32_t idx = (uint32_t)(c * 64 + lane);
-                if (c < NCH - 1 || idx < a.row_vecs) {
-                    x[u][c] = load_vec<NT>(rp + idx);
-                } else {
-                    x[u][c] = u32x4{0u, 0u, 0u, 0u};
-                }
+    uint32_t turn = 0;
+    for (uint32_t y = y0; y < a.n_q; y += y_step, ++turn) {
+        const uint64_t* cand = a.cand_of ? a.cand_of[y] : a.cand;
+        if (a.cand_of) {
+            W = W0;
+            w = w0;
+            idle = have_first = false;
+            if (a.pair && cand) {
+                idle = pair_up_waves(a.present, cand, a.n_slots, lane, wib, 1, 6, &w, &W, &first_batch);
+                have_first = true;
             }
-            pn[u] = METRIC == VS_ANGULAR ? a.norms[slot[u]] : 0.0f;
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            float acc = 0.0f;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c)
-                acc = METRIC == VS_EUCLIDEAN ? sqdiff_vec<ELEM>(x[u][c], q[c], acc)
-                                             : dot_vec<ELEM>(x[u][c], q[c], acc);
-            const float pq = wave_sum_f32(acc);
-            const float d = METRIC == VS_ANGULAR     ? angular_distance(pq, pn[u], qn)
-                            : METRIC == VS_EUCLIDEAN ? pq
-                                                     : -pq;
-            const uint64_t key = make_key(uniform_u32(f32_orderable(d)), a.docid_base + slot[u]);
-            if ((uint32_t)u < nvalid && key < top.tau) top.insert(key);
-        }
-    };
+        unsigned char* lists = smem + (a.list_bufs > 1 ? (turn & 1) * list_bytes : 0);
+        WaveTopK top;
+        top.init(reinterpret_cast<uint64_t*>(lists) + (size_t)wib * k, k, lane);
 
-    if (!idle)
-        scan_masked_slots<U>(a.present, a.cand, a.n_slots, w, W, lane, queue, score_rows, NoDenseFn(), EveryWord(),
-                             have_first, first_batch);
-    finish_block(top, smem, k, wib, lane, a.partial);
+        // this lane's slice of the query, and ‖q‖ summed in the row order
+        const float* query = a.query + (size_t)y * a.query_stride;
+        float q[NCH][EPV];
+        float qq = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) {
+                const uint32_t e = (uint32_t)(c * 64 + lane) * EPV + j;
+                q[c][j] = e < a.dim ? query[e] : 0.0f;
+                qq = __builtin_fmaf(q[c][j], q[c][j], qq);
+            }
+        }
+        const float qn = sqrtf(wave_sum_f32(qq));
+        wave_lds_fence();
+
+        // Scores rows queue[head .. head+U); the first `nvalid` of them count.
+        auto score_rows = [&](uint32_t head, uint32_t nvalid) {
+            uint32_t slot[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t at = head + ((uint32_t)u < nvalid ? (uint32_t)u : nvalid - 1);
+                slot[u] = uniform_u32(queue[at]);
+            }
+            u32x4 x[U][NCH];
+            float pn[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const u32x4* rp = a.rows + (uint64_t)slot[u] * a.row_vecs;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const uint32_t idx = (uint32_t)(c * 64 + lane);
+                    if (c < NCH - 1 || idx < a.row_vecs) {
+                        x[u][c] = load_vec<NT>(rp + idx);
+                    } else {
+                        x[u][c] = u32x4{0u, 0u, 0u, 0u};
+                    }
+                }
+                pn[u] = METRIC == VS_ANGULAR ? a.norms[slot[u]] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+                    acc = METRIC == VS_EUCLIDEAN ? sqdiff_vec<ELEM>(x[u][c], q[c], acc)
+                                                 : dot_vec<ELEM>(x[u][c], q[c], acc);
+                const float pq = wave_sum_f32(acc);
+                const float d = METRIC == VS_ANGULAR     ? angular_distance(pq, pn[u], qn)
+                                : METRIC == VS_EUCLIDEAN ? pq
+                                                         : -pq;
+                const uint64_t key = make_key(uniform_u32(f32_orderable(d)), a.docid_base + slot[u]);
+                if ((uint32_t)u < nvalid && key < top.tau) top.insert(key);
+            }
+        };
+
+        if (!idle)
+            scan_masked_slots<U>(a.present, cand, a.n_slots, w, W, lane, queue, score_rows, NoDenseFn(), EveryWord(),
+                                 have_first, first_batch);
+        finish_block(top, lists, k, wib, lane, a.partial + (uint64_t)y * a.partial_stride);
+        // one list buffer only: wave 0 must be through with it before the next query's lists go there
+        if (a.list_bufs < 2 && y + y_step < a.n_q) __syncthreads();
+    }
 }
 
 template <int ELEM, int NCH, int U, bool NT>
@@ -967,6 +1046,12 @@ struct HammingArgs {
     uint32_t k;
     uint32_t park = 0;  // non-zero: candidates are parked and merged in batches (WaveTopK::park)
     uint32_t pair = 0;  // non-zero: workgroups b and b + gridDim.x / 2 share their mask words (pair_up_waves)
+    // several independent queries in one launch, as in ScanArgs
+    uint32_t n_q = 1;
+    uint32_t query_stride = 0;    // 16-byte vectors between consecutive queries
+    uint64_t partial_stride = 0;  // keys between consecutive queries' partial lists
+    const uint64_t* const* cand_of = nullptr;
+    uint32_t list_bufs = 1;
 };
 
 // Dense stretches of 192-byte rows. A row is one and a half 128-byte lines, so the quad
@@ -1042,95 +1127,121 @@ __global__ __launch_bounds__(WAVES * 64) void scan_hamming_kernel(HammingArgs a)
     const int lane = threadIdx.x & 63;
     const int quad = lane >> 2, sub = lane & 3;
     const uint32_t wib = uniform_u32(threadIdx.x >> 6);
-    uint32_t W = gridDim.x * WAVES;
-    uint32_t w = blockIdx.x * WAVES + wib;
+    const uint32_t W0 = gridDim.x * WAVES, w0 = blockIdx.x * WAVES + wib;
     const int k = (int)a.k;
-    uint32_t* queue =
-        reinterpret_cast<uint32_t*>(smem + (size_t)WAVES * k * 8) + (size_t)wib * QCAP;
-    WaveTopK top;
-    top.init(reinterpret_cast<uint64_t*>(smem) + (size_t)wib * k, k, lane);
+    const size_t list_bytes = (size_t)WAVES * k * 8;
+    uint32_t* queue = reinterpret_cast<uint32_t*>(smem + a.list_bufs * list_bytes) + (size_t)wib * QCAP;
+    // (the launcher adds the buffers of the batched insertion behind the queues)
+    uint64_t* park_buffer =
+        reinterpret_cast<uint64_t*>(smem + a.list_bufs * list_bytes + (size_t)WAVES * QCAP * 4) + (size_t)wib * 128;
     // paired launch: where nearly every slot is a candidate (the whole-word path below) one wave per
-    // SIMD streams faster (50 M x 1536 bit, all-ones mask: 6.94 against 6.78 TB/s)
+    // SIMD streams faster (50 M x 1536 bit, all-ones mask: 6.94 against 6.78 TB/s). The decision
+    // depends on the mask alone: taken once when all queries share it.
+    uint32_t W = W0, w = w0;
     bool idle = false, have_first = false;
     uint64_t first_batch = 0;
-    if (a.pair) {
-        idle = pair_up_waves(a.present, a.cand, a.n_slots, lane, wib, 7, 8, &w, &W, &first_batch);
+    bool dense = a.cand == nullptr;
+    if (a.pair && !a.cand_of) {
+        idle = pair_up_waves(a.present, a.cand, a.n_slots, lane, wib, 7, 8, &w, &W, &first_batch, &dense);
         have_first = true;
+    } else if (gridDim.y > 1 && a.cand && !a.cand_of) {
+        first_batch = first_mask_words(a.present, a.cand, a.n_slots, w, W, lane);
+        have_first = true;
+        dense = sample_is_dense(first_batch, a.n_slots, w, W, 7, 8);
     }
-    if (a.park)  // (the launcher adds the buffers behind the queues)
-        top.park_in(reinterpret_cast<uint64_t*>(smem + (size_t)WAVES * k * 8 + (size_t)WAVES * QCAP * 4) + (size_t)wib * 128);
+    uint32_t y0, y_step;
+    if (!split_queries(dense && !a.cand_of, &y0, &y_step)) return;
 
-    // this lane's share of the query: vectors sub, sub + 4, ...
-    u32x4 q[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const uint32_t p = (uint32_t)(i * 4 + sub);
-        q[i] = p < a.row_vecs ? a.query[p] : u32x4{0u, 0u, 0u, 0u};
-    }
+    uint32_t turn = 0;
+    for (uint32_t y = y0; y < a.n_q; y += y_step, ++turn) {
+        const uint64_t* cand = a.cand_of ? a.cand_of[y] : a.cand;
+        if (a.cand_of) {
+            W = W0;
+            w = w0;
+            idle = have_first = false;
+            if (a.pair && cand) {
+                idle = pair_up_waves(a.present, cand, a.n_slots, lane, wib, 7, 8, &w, &W, &first_batch);
+                have_first = true;
+            }
+        }
+        unsigned char* lists = smem + (a.list_bufs > 1 ? (turn & 1) * list_bytes : 0);
+        WaveTopK top;
+        top.init(reinterpret_cast<uint64_t*>(lists) + (size_t)wib * k, k, lane);
+        if (a.park) top.park_in(park_buffer);
 
-    auto score_rows = [&](uint32_t head, uint32_t nvalid) {
-        uint32_t slot[U];
-        bool valid[U];
-        u32x4 x[U][NI];
+        // this lane's share of the query: vectors sub, sub + 4, ...
+        const u32x4* query = a.query + (size_t)y * a.query_stride;
+        u32x4 q[NI];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t r = (uint32_t)(u * 16 + quad);
-            valid[u] = r < nvalid;
-            slot[u] = queue[head + (valid[u] ? r : 0u)];
-            const u32x4* rp = a.rows + (uint64_t)slot[u] * a.row_vecs;
+        for (int i = 0; i < NI; ++i) {
+            const uint32_t p = (uint32_t)(i * 4 + sub);
+            q[i] = p < a.row_vecs ? query[p] : u32x4{0u, 0u, 0u, 0u};
+        }
+
+        auto score_rows = [&](uint32_t head, uint32_t nvalid) {
+            uint32_t slot[U];
+            bool valid[U];
+            u32x4 x[U][NI];
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const uint32_t p = (uint32_t)(i * 4 + sub);
-                if (i < NI - 1 || p < a.row_vecs) {
-                    x[u][i] = load_vec<NT>(rp + p);
-                } else {
-                    x[u][i] = u32x4{0u, 0u, 0u, 0u};
+            for (int u = 0; u < U; ++u) {
+                const uint32_t r = (uint32_t)(u * 16 + quad);
+                valid[u] = r < nvalid;
+                slot[u] = queue[head + (valid[u] ? r : 0u)];
+                const u32x4* rp = a.rows + (uint64_t)slot[u] * a.row_vecs;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const uint32_t p = (uint32_t)(i * 4 + sub);
+                    if (i < NI - 1 || p < a.row_vecs) {
+                        x[u][i] = load_vec<NT>(rp + p);
+                    } else {
+                        x[u][i] = u32x4{0u, 0u, 0u, 0u};
+                    }
                 }
             }
-        }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            uint32_t cnt = 0;
+            for (int u = 0; u < U; ++u) {
+                uint32_t cnt = 0;
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
+                for (int i = 0; i < NI; ++i) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) cnt += (uint32_t)__popc(x[u][i][j] ^ q[i][j]);
+                    for (int j = 0; j < 4; ++j) cnt += (uint32_t)__popc(x[u][i][j] ^ q[i][j]);
+                }
+                cnt += dpp_u32<0xB1, 0xF>(cnt);  // quad_perm [1,0,3,2]
+                cnt += dpp_u32<0x4E, 0xF>(cnt);  // quad_perm [2,3,0,1]
+                const uint64_t key = make_key(cnt, a.docid_base + slot[u]);
+                const bool live = valid[u] && sub == 0;
+                if (top.parks()) {
+                    top.park(live && key < top.tau, key);
+                    continue;
+                }
+                uint64_t m = __ballot(live && key < top.tau);
+                while (m) {
+                    const int src = __builtin_ctzll(m);
+                    top.insert(readlane_u64(key, src));
+                    m &= m - 1;
+                    m &= __ballot(live && key < top.tau);
+                }
             }
-            cnt += dpp_u32<0xB1, 0xF>(cnt);  // quad_perm [1,0,3,2]
-            cnt += dpp_u32<0x4E, 0xF>(cnt);  // quad_perm [2,3,0,1]
-            const uint64_t key = make_key(cnt, a.docid_base + slot[u]);
-            const bool live = valid[u] && sub == 0;
-            if (top.parks()) {
-                top.park(live && key < top.tau, key);
-                continue;
-            }
-            uint64_t m = __ballot(live && key < top.tau);
-            while (m) {
-                const int src = __builtin_ctzll(m);
-                top.insert(readlane_u64(key, src));
-                m &= m - 1;
-                m &= __ballot(live && key < top.tau);
-            }
-        }
-    };
+        };
 
-    if constexpr (NI == 3) {
-        if (a.row_vecs == 12) {  // 1536-bit rows: whole words of candidates go through the pair path
-            HammingPairs<NT> pairs{a.rows, a.docid_base, lane, &top};
-            pairs.load_query(a.query);
-            if (!idle)
-                scan_masked_slots<16 * U>(a.present, a.cand, a.n_slots, w, W, lane, queue, score_rows, pairs,
-                                          EveryWord(), have_first, first_batch);
-            top.merge_parked();
-            finish_block(top, smem, k, wib, lane, a.partial);
-            return;
+        bool scanned = false;
+        if constexpr (NI == 3) {
+            if (a.row_vecs == 12) {  // 1536-bit rows: whole words of candidates go through the pair path
+                HammingPairs<NT> pairs{a.rows, a.docid_base, lane, &top};
+                pairs.load_query(query);
+                if (!idle)
+                    scan_masked_slots<16 * U>(a.present, cand, a.n_slots, w, W, lane, queue, score_rows, pairs,
+                                              EveryWord(), have_first, first_batch);
+                scanned = true;
+            }
         }
+        if (!scanned && !idle)
+            scan_masked_slots<16 * U>(a.present, cand, a.n_slots, w, W, lane, queue, score_rows, NoDenseFn(),
+                                      EveryWord(), have_first, first_batch);
+        top.merge_parked();
+        finish_block(top, lists, k, wib, lane, a.partial + (uint64_t)y * a.partial_stride);
+        if (a.list_bufs < 2 && y + y_step < a.n_q) __syncthreads();
     }
-    if (!idle)
-        scan_masked_slots<16 * U>(a.present, a.cand, a.n_slots, w, W, lane, queue, score_rows, NoDenseFn(),
-                                  EveryWord(), have_first, first_batch);
-    top.merge_parked();
-    finish_block(top, smem, k, wib, lane, a.partial);
 }
 
 // ---- Hamming scan, four queries per pass ------------------------------------------------
@@ -1539,9 +1650,9 @@ uint64_t scan_workspace_bytes(const SlabView& s, uint32_t k) {
 }
 
 template <int ELEM, int NCH, int U>
-static hipError_t launch_scan_t(const ScanArgs& a, uint32_t blocks, size_t lds, const ScanTuning& t,
+static hipError_t launch_scan_t(const ScanArgs& a, uint32_t blocks, uint32_t lanes, size_t lds, const ScanTuning& t,
                                 hipStream_t stream) {
-    const dim3 grid(blocks), block(WAVES * 64);
+    const dim3 grid(blocks, lanes), block(WAVES * 64);
     if (a.metric == VS_EUCLIDEAN)
         hipLaunchKernelGGL((scan_euclidean_kernel<ELEM, NCH, U>), grid, block, lds, stream, a);
     else if (a.metric == VS_DOT)
@@ -1554,43 +1665,50 @@ static hipError_t launch_scan_t(const ScanArgs& a, uint32_t blocks, size_t lds, 
 }
 
 template <int ELEM>
-static hipError_t launch_scan_e(const ScanArgs& a, uint32_t blocks, size_t lds, const ScanTuning& t,
+static hipError_t launch_scan_e(const ScanArgs& a, uint32_t blocks, uint32_t lanes, size_t lds, const ScanTuning& t,
                                 hipStream_t stream) {
     const uint32_t nch = (a.row_vecs + 63) / 64;
-    if (nch <= 1) return launch_scan_t<ELEM, 1, 8>(a, blocks, lds, t, stream);
+    if (nch <= 1) return launch_scan_t<ELEM, 1, 8>(a, blocks, lanes, lds, t, stream);
     if (nch <= 2) {
         if (a.metric == VS_ANGULAR) {  // schedule probes, angular only
-            if (t.rows_in_flight == 4) return launch_scan_t<ELEM, 2, 4>(a, blocks, lds, t, stream);
-            if (t.rows_in_flight == 16) return launch_scan_t<ELEM, 2, 16>(a, blocks, lds, t, stream);
+            if (t.rows_in_flight == 4) return launch_scan_t<ELEM, 2, 4>(a, blocks, lanes, lds, t, stream);
+            if (t.rows_in_flight == 16) return launch_scan_t<ELEM, 2, 16>(a, blocks, lanes, lds, t, stream);
         }
-        return launch_scan_t<ELEM, 2, 8>(a, blocks, lds, t, stream);
+        return launch_scan_t<ELEM, 2, 8>(a, blocks, lanes, lds, t, stream);
     }
     if (nch <= 3) {
         if (a.metric == VS_ANGULAR) {  // schedule probes, angular only
-            if (t.rows_in_flight == 2) return launch_scan_t<ELEM, 3, 2>(a, blocks, lds, t, stream);
-            if (t.rows_in_flight == 8) return launch_scan_t<ELEM, 3, 8>(a, blocks, lds, t, stream);
+            if (t.rows_in_flight == 2) return launch_scan_t<ELEM, 3, 2>(a, blocks, lanes, lds, t, stream);
+            if (t.rows_in_flight == 8) return launch_scan_t<ELEM, 3, 8>(a, blocks, lanes, lds, t, stream);
         }
-        return launch_scan_t<ELEM, 3, 4>(a, blocks, lds, t, stream);
+        return launch_scan_t<ELEM, 3, 4>(a, blocks, lanes, lds, t, stream);
     }
-    if (nch <= 4) return launch_scan_t<ELEM, 4, 4>(a, blocks, lds, t, stream);
-    if (nch <= 6) return launch_scan_t<ELEM, 6, 2>(a, blocks, lds, t, stream);
-    if (nch <= 8) return launch_scan_t<ELEM, 8, 2>(a, blocks, lds, t, stream);
-    if (nch <= 12) return launch_scan_t<ELEM, 12, 1>(a, blocks, lds, t, stream);
-    if (nch <= 16) return launch_scan_t<ELEM, 16, 1>(a, blocks, lds, t, stream);
+    if (nch <= 4) return launch_scan_t<ELEM, 4, 4>(a, blocks, lanes, lds, t, stream);
+    if (nch <= 6) return launch_scan_t<ELEM, 6, 2>(a, blocks, lanes, lds, t, stream);
+    if (nch <= 8) return launch_scan_t<ELEM, 8, 2>(a, blocks, lanes, lds, t, stream);
+    if (nch <= 12) return launch_scan_t<ELEM, 12, 1>(a, blocks, lanes, lds, t, stream);
+    if (nch <= 16) return launch_scan_t<ELEM, 16, 1>(a, blocks, lanes, lds, t, stream);
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_scan_float(const SlabView& s, const float* d_query, const uint64_t* cand,
-                               uint32_t k, uint64_t* partial, uint64_t* out_keys,
-                               uint32_t* out_ids, float* out_dist, uint32_t* out_n,
-                               const ScanTuning& t, hipStream_t stream) {
-    if (k == 0 || k > VS_MAX_K || (s.n_slots & 63) || s.n_slots == 0) return hipErrorInvalidValue;
+// Query lanes of a many-query launch (gridDim.y, see split_queries): four by default, which the
+// workgroups themselves reduce to one where the filter is dense.
+static uint32_t scan_query_lanes(uint32_t n_q, const ScanTuning& t) {
+    const uint32_t lanes = t.query_lanes > 0 ? (uint32_t)t.query_lanes : 4u;
+    return lanes < n_q ? lanes : n_q;
+}
+
+hipError_t launch_scan_float_queries(const SlabView& s, const float* d_queries, uint32_t query_stride,
+                                     uint32_t n_q, const uint64_t* cand, const uint64_t* const* d_cand_of,
+                                     uint32_t k, uint64_t* partial, const ScanTuning& t, hipStream_t stream) {
+    if (k == 0 || k > VS_MAX_K || (s.n_slots & 63) || s.n_slots == 0 || n_q == 0) return hipErrorInvalidValue;
+    const bool masked = cand != nullptr || d_cand_of != nullptr;
     ScanArgs a;
     a.rows = reinterpret_cast<const u32x4*>(s.rows);
     a.norms = s.norms;
     a.present = s.present;
     a.cand = cand;
-    a.query = d_query;
+    a.query = d_queries;
     a.partial = partial;
     a.n_slots = s.n_slots;
     a.row_vecs = s.row_vecs;
@@ -1601,29 +1719,39 @@ hipError_t launch_scan_float(const SlabView& s, const float* d_query, const uint
     if (s.metric != VS_ANGULAR && s.metric != VS_EUCLIDEAN && s.metric != VS_DOT)
         return hipErrorInvalidValue;
     if (s.metric == VS_ANGULAR && !s.norms) return hipErrorInvalidValue;
-    const uint32_t blocks = scan_grid_blocks(s, t, cand != nullptr);
+    const uint32_t blocks = scan_grid_blocks(s, t, masked);
     // the default grid under a filter is two workgroups per CU: let them pair up (see scan_float_rows)
-    a.pair = (cand != nullptr && t.blocks <= 0 && blocks >= 2 && !(blocks & 1) && float_rows_stream_with_one_wave(s))
+    a.pair = (masked && t.blocks <= 0 && blocks >= 2 && !(blocks & 1) && float_rows_stream_with_one_wave(s))
                  ? 1u
                  : 0u;
-    const size_t lds = (size_t)WAVES * k * 8 + (size_t)WAVES * QCAP * 4;
-    hipError_t e;
-    if (s.dtype == VS_F32)
-        e = launch_scan_e<VS_F32>(a, blocks, lds, t, stream);
-    else if (s.dtype == VS_BF16)
-        e = launch_scan_e<VS_BF16>(a, blocks, lds, t, stream);
-    else
-        return hipErrorInvalidValue;
+    const uint32_t lanes = scan_query_lanes(n_q, t);
+    a.n_q = n_q;
+    a.query_stride = query_stride;
+    a.partial_stride = (uint64_t)blocks * k;
+    a.cand_of = d_cand_of;
+    a.list_bufs = (n_q > 1 && k <= (uint32_t)WaveTopK::REG_K) ? 2u : 1u;
+    const size_t lds = (size_t)a.list_bufs * WAVES * k * 8 + (size_t)WAVES * QCAP * 4;
+    if (s.dtype == VS_F32) return launch_scan_e<VS_F32>(a, blocks, lanes, lds, t, stream);
+    if (s.dtype == VS_BF16) return launch_scan_e<VS_BF16>(a, blocks, lanes, lds, t, stream);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_scan_float(const SlabView& s, const float* d_query, const uint64_t* cand,
+                               uint32_t k, uint64_t* partial, uint64_t* out_keys,
+                               uint32_t* out_ids, float* out_dist, uint32_t* out_n,
+                               const ScanTuning& t, hipStream_t stream) {
+    const hipError_t e = launch_scan_float_queries(s, d_query, 0, 1, cand, nullptr, k, partial, t, stream);
     if (e != hipSuccess) return e;
     if (!out_keys && !out_ids) return hipSuccess;  // partial lists only: the caller merges
+    const uint32_t blocks = scan_grid_blocks(s, t, cand != nullptr);
     return launch_merge(partial, blocks, 1, blocks, k, s.metric, out_keys, out_ids, out_dist,
                         out_n, stream);
 }
 
 template <int NI, int U>
-static hipError_t launch_hamming_t(const HammingArgs& a, uint32_t blocks, size_t lds,
+static hipError_t launch_hamming_t(const HammingArgs& a, uint32_t blocks, uint32_t lanes, size_t lds,
                                    const ScanTuning& t, hipStream_t stream) {
-    const dim3 grid(blocks), block(WAVES * 64);
+    const dim3 grid(blocks, lanes), block(WAVES * 64);
     if (t.nt)
         hipLaunchKernelGGL((scan_hamming_kernel<NI, U, true>), grid, block, lds, stream, a);
     else
@@ -1631,17 +1759,17 @@ static hipError_t launch_hamming_t(const HammingArgs& a, uint32_t blocks, size_t
     return hipGetLastError();
 }
 
-hipError_t launch_scan_hamming(const SlabView& s, const void* d_query, const uint64_t* cand,
-                               uint32_t k, uint64_t* partial, uint64_t* out_keys,
-                               uint32_t* out_ids, float* out_dist, uint32_t* out_n,
-                               const ScanTuning& t, hipStream_t stream) {
-    if (k == 0 || k > VS_MAX_K || (s.n_slots & 63) || s.n_slots == 0 || s.dtype != VS_BIN1)
+hipError_t launch_scan_hamming_queries(const SlabView& s, const void* d_queries, uint32_t query_stride,
+                                       uint32_t n_q, const uint64_t* cand, const uint64_t* const* d_cand_of,
+                                       uint32_t k, uint64_t* partial, const ScanTuning& t, hipStream_t stream) {
+    if (k == 0 || k > VS_MAX_K || (s.n_slots & 63) || s.n_slots == 0 || s.dtype != VS_BIN1 || n_q == 0)
         return hipErrorInvalidValue;
+    const bool masked = cand != nullptr || d_cand_of != nullptr;
     HammingArgs a;
     a.rows = reinterpret_cast<const u32x4*>(s.rows);
     a.present = s.present;
     a.cand = cand;
-    a.query = reinterpret_cast<const u32x4*>(d_query);
+    a.query = reinterpret_cast<const u32x4*>(d_queries);
     a.partial = partial;
     a.n_slots = s.n_slots;
     a.row_vecs = s.row_vecs;
@@ -1649,25 +1777,38 @@ hipError_t launch_scan_hamming(const SlabView& s, const void* d_query, const uin
     a.k = k;
     // top-100 under a filter: an insert at a time was 30 to 40 us of every launch (50 M x 1536 bit)
     a.park = (k > 32 && k <= (uint32_t)WaveTopK::REG_K) ? 1u : 0u;
-    const uint32_t blocks = scan_grid_blocks(s, t, cand != nullptr);
+    const uint32_t blocks = scan_grid_blocks(s, t, masked);
     // the default grid under a filter is two workgroups per CU: let them pair up where the rows
     // have the whole-word path (1536 bits)
-    a.pair = (cand != nullptr && t.blocks <= 0 && blocks >= 2 && !(blocks & 1) && s.row_vecs == 12) ? 1u : 0u;
-    const size_t lds = (size_t)WAVES * k * 8 + (size_t)WAVES * QCAP * 4 + (a.park ? (size_t)WAVES * 128 * 8 : 0);
+    a.pair = (masked && t.blocks <= 0 && blocks >= 2 && !(blocks & 1) && s.row_vecs == 12) ? 1u : 0u;
+    const uint32_t lanes = scan_query_lanes(n_q, t);
+    a.n_q = n_q;
+    a.query_stride = query_stride;
+    a.partial_stride = (uint64_t)blocks * k;
+    a.cand_of = d_cand_of;
+    a.list_bufs = (n_q > 1 && k <= (uint32_t)WaveTopK::REG_K) ? 2u : 1u;
+    const size_t lds = (size_t)a.list_bufs * WAVES * k * 8 + (size_t)WAVES * QCAP * 4 + (a.park ? (size_t)WAVES * 128 * 8 : 0);
     const uint32_t ni = (s.row_vecs + 3) / 4;
-    hipError_t e;
-    if (ni <= 1) e = launch_hamming_t<1, 4>(a, blocks, lds, t, stream);
-    else if (ni <= 2) e = launch_hamming_t<2, 4>(a, blocks, lds, t, stream);
-    else if (ni <= 3) {
-        if (t.rows_in_flight == 2) e = launch_hamming_t<3, 2>(a, blocks, lds, t, stream);
-        else if (t.rows_in_flight == 8) e = launch_hamming_t<3, 8>(a, blocks, lds, t, stream);
-        else e = launch_hamming_t<3, 4>(a, blocks, lds, t, stream);
+    if (ni <= 1) return launch_hamming_t<1, 4>(a, blocks, lanes, lds, t, stream);
+    if (ni <= 2) return launch_hamming_t<2, 4>(a, blocks, lanes, lds, t, stream);
+    if (ni <= 3) {
+        if (t.rows_in_flight == 2) return launch_hamming_t<3, 2>(a, blocks, lanes, lds, t, stream);
+        if (t.rows_in_flight == 8) return launch_hamming_t<3, 8>(a, blocks, lanes, lds, t, stream);
+        return launch_hamming_t<3, 4>(a, blocks, lanes, lds, t, stream);
     }
-    else if (ni <= 4) e = launch_hamming_t<4, 2>(a, blocks, lds, t, stream);
-    else if (ni <= 8) e = launch_hamming_t<8, 2>(a, blocks, lds, t, stream);
-    else return hipErrorInvalidValue;
+    if (ni <= 4) return launch_hamming_t<4, 2>(a, blocks, lanes, lds, t, stream);
+    if (ni <= 8) return launch_hamming_t<8, 2>(a, blocks, lanes, lds, t, stream);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_scan_hamming(const SlabView& s, const void* d_query, const uint64_t* cand,
+                               uint32_t k, uint64_t* partial, uint64_t* out_keys,
+                               uint32_t* out_ids, float* out_dist, uint32_t* out_n,
+                               const ScanTuning& t, hipStream_t stream) {
+    const hipError_t e = launch_scan_hamming_queries(s, d_query, 0, 1, cand, nullptr, k, partial, t, stream);
     if (e != hipSuccess) return e;
     if (!out_keys && !out_ids) return hipSuccess;  // partial lists only: the caller merges
+    const uint32_t blocks = scan_grid_blocks(s, t, cand != nullptr);
     return launch_merge(partial, blocks, 1, blocks, k, VS_HAMMING, out_keys, out_ids, out_dist,
                         out_n, stream);
 }

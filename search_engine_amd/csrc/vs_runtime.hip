@@ -99,6 +99,7 @@ vs::ScanTuning tuning_of(const vs_ctx* ctx) {
     t.blocks = ctx->tune_blocks.load(std::memory_order_relaxed);
     t.nt = ctx->tune_nt.load(std::memory_order_relaxed);
     t.rows_in_flight = ctx->tune_rows.load(std::memory_order_relaxed);
+    t.query_lanes = ctx->tune_qlanes.load(std::memory_order_relaxed);
     return t;
 }
 
@@ -159,6 +160,18 @@ int32_t launch_scan(const vs::SlabView& v, const vs::ScanTuning& t, const void* 
     else
         HIP_TRY(vs::launch_scan_float(v, static_cast<const float*>(d_query), d_cand, k, d_partial, d_keys, d_ids,
                                       d_dist, d_n, t, stream));
+    return VS_OK;
+}
+
+int32_t launch_scan_queries(const vs::SlabView& v, const vs::ScanTuning& t, const void* d_queries,
+                            size_t query_bytes, uint32_t n_q, const uint64_t* d_cand,
+                            const uint64_t* const* d_cand_of, uint32_t k, uint64_t* d_partial, hipStream_t stream) {
+    if (v.metric == VS_HAMMING)
+        HIP_TRY(vs::launch_scan_hamming_queries(v, d_queries, (uint32_t)(query_bytes / 16), n_q, d_cand, d_cand_of, k,
+                                                d_partial, t, stream));
+    else
+        HIP_TRY(vs::launch_scan_float_queries(v, static_cast<const float*>(d_queries), (uint32_t)(query_bytes / 4),
+                                              n_q, d_cand, d_cand_of, k, d_partial, t, stream));
     return VS_OK;
 }
 
@@ -529,6 +542,7 @@ extern "C" int32_t vs_init(int32_t device_ordinal, vs_ctx** out) {
     env_int("VS_SCAN_BLOCKS", 0, vs::MAX_TUNED_BLOCKS, &ctx->tune_blocks);
     env_int("VS_SCAN_NT", 0, 1, &ctx->tune_nt);
     env_int("VS_SCAN_ROWS", 0, 16, &ctx->tune_rows);
+    env_int("VS_SCAN_QLANES", 0, 16, &ctx->tune_qlanes);
     HIP_TRY(hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
     HIP_TRY(hipHostMalloc(&ctx->h_small, 64 << 10, hipHostMallocDefault));
     // device `device_ordinal` is current: this is its copy of the array

@@ -154,3 +154,64 @@ def test_sharded_search_in_a_group_of_one(gpu_ctx, dtype_name, flags_name):
     finally:
         group.destroy()
         store.destroy()
+
+
+@pytest.mark.parametrize("k", [10, 200])
+@pytest.mark.parametrize("pass_percent", [100, 50, 3])
+@pytest.mark.parametrize("shape", ["f32_768", "f32_96", "bf16_768", "bin1_1536", "bin1_256"])
+def test_a_step_of_queries_in_one_launch_equals_their_own_searches(gpu_ctx, shape, pass_percent, k):
+    """vs_search_sharded_device without VS_SHARDED_SHARE_PASSES runs ONE scan launch for all queries of
+    the step (a workgroup takes its share of the mask words for one query after the other, several
+    queries in flight under a selective filter, one where the filter is dense). No row read is shared,
+    so every list must be bit for bit the list of the query's own vs_search_device: long rows (paired
+    workgroups), short rows, binary rows with and without the whole-word path, lists in registers
+    (k = 10) and in LDS (k = 200), query counts that do and do not fill the lanes."""
+    from search_engine_amd import abi
+    dtype_name, dim = shape.split("_")
+    dim = int(dim)
+    dtype, metric = {"f32": (abi.VS_F32, abi.VS_ANGULAR), "bf16": (abi.VS_BF16, abi.VS_ANGULAR),
+                     "bin1": (abi.VS_BIN1, abi.VS_HAMMING)}[dtype_name]
+    n = 150_000 if dtype_name != "bin1" else 600_000
+    stream = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(11)
+    if dtype_name == "bin1":
+        rows = torch.randint(-(1 << 31), 1 << 31, (n, dim // 32), generator=gen, device=DEV, dtype=torch.int64).to(torch.int32)
+        queries = torch.randint(-(1 << 31), 1 << 31, (16, dim // 32), generator=gen, device=DEV, dtype=torch.int64).to(torch.int32)
+    else:
+        tdt = torch.float32 if dtype_name == "f32" else torch.bfloat16
+        rows = torch.randn(n, dim, generator=gen, device=DEV).to(tdt)
+        queries = torch.randn(16, dim, generator=gen, device=DEV)
+    n_slots = -(-n // 64) * 64
+    d_mask = torch.from_numpy(facet_mask(n_slots, pass_percent).view(np.int64)).to(DEV)
+    store = gpu_ctx.create_store(830, dim, n, dtype=dtype, metric=metric)
+    group = abi.Group(gpu_ctx, 0, 1, abi.group_unique_id())
+    try:
+        store.upload_device(0, rows.data_ptr(), n, stream)
+        torch.cuda.synchronize()
+        store.seal()
+        ws = torch.empty(store.workspace_bytes(k), dtype=torch.uint8, device=DEV)
+        for n_q, masked in ((16, True), (5, True), (7, False), (1, True)):
+            mask_ptr = d_mask.data_ptr() if masked else 0
+            want = torch.zeros(n_q * k, dtype=torch.int64, device=DEV)
+            for j in range(n_q):
+                store.search_device(queries[j].data_ptr(), dim, k, mask_ptr, ws.data_ptr(), want[j * k:].data_ptr(), stream)
+            ids = torch.zeros(n_q * k, dtype=torch.int32, device=DEV)
+            dist = torch.zeros(n_q * k, dtype=torch.float32, device=DEV)
+            cnt = torch.zeros(n_q, dtype=torch.int32, device=DEV)
+            group.search_sharded_device(store, queries.data_ptr(), n_q, dim, k, mask_ptr, 0,
+                                        ids.data_ptr(), dist.data_ptr(), cnt.data_ptr(), stream)
+            torch.cuda.synchronize()
+            want = want.cpu().numpy().view(np.uint64).reshape(n_q, k)
+            got = ids.cpu().numpy().view(np.uint32).reshape(n_q, k)
+            assert (cnt.cpu().numpy() == k).all()
+            assert got.tolist() == (want & np.uint64(0xFFFFFFFF)).astype(np.uint32).tolist(), (n_q, masked)
+            if metric == abi.VS_ANGULAR:  # the key's upper half is the orderable distance: decode and compare bits
+                hi = (want >> np.uint64(32)).astype(np.uint32)
+                bits = np.where(hi & np.uint32(0x80000000), hi & np.uint32(0x7FFFFFFF), ~hi)
+                assert dist.cpu().numpy().view(np.uint32).reshape(n_q, k).tolist() == bits.tolist()
+            else:
+                assert dist.cpu().numpy().reshape(n_q, k).tolist() == (want >> np.uint64(32)).astype(np.float32).tolist()
+    finally:
+        group.destroy()
+        store.destroy()
