@@ -287,14 +287,17 @@ int32_t vs_search_workspace_bytes(vs_store* s, uint32_t k, uint64_t* bytes);
  *                 vs_store_row_bytes bytes, zero padded
  *   d_mask_words: candidate words ALIGNED TO THE STORE: word j covers docids
  *                 docid_base + 64 j .. ; capacity/64 words; NULL = every item
- *   d_workspace:  vs_search_workspace_bytes bytes, private to this call until
- *                 the stream has passed it
+ *   d_workspace:  `workspace_bytes` bytes, private to this call until the stream
+ *                 has passed it. The call checks the size against what the store
+ *                 needs NOW and returns VS_E_CAPACITY if it is short: sizes
+ *                 grow with the store, so ask vs_search_workspace_bytes again
+ *                 after a vs_store_reserve
  *   d_out_keys:   k u64 keys, ascending; key = (orderable(distance) << 32) |
  *                 docid, padded with VS_KEY_NONE. This is the shard-local
  *                 top-k a multi-GPU caller all-gathers. */
 int32_t vs_search_device(vs_store* s, const void* d_query, uint32_t dim, uint32_t k,
-                         const uint64_t* d_mask_words, void* d_workspace, uint64_t* d_out_keys,
-                         void* hip_stream);
+                         const uint64_t* d_mask_words, void* d_workspace, uint64_t workspace_bytes,
+                         uint64_t* d_out_keys, void* hip_stream);
 
 /* No counterpart in the reference. vs_search_device for callers that cannot
  * allocate device memory or pass a workspace: code under HIP graph capture, tight
@@ -331,11 +334,13 @@ int32_t vs_search_device_noalloc(vs_store* s, const void* d_query, uint32_t dim,
  *     PACKED queries of vs_store_row_bytes bytes each (as vs_search_device takes
  *     one); four share a pass, lists equal to vs_search_device's;
  *   - anything else: VS_E_INVALID_ARG (use vs_search_device per query).
+ * `workspace_bytes` is checked against vs_search_batch_workspace_bytes for the
+ * store as it is now (VS_E_CAPACITY if short; the need grows with the store).
  * No reference counterpart (the reference searches one vector per request). */
 int32_t vs_search_batch_workspace_bytes(vs_store* s, uint32_t k, uint64_t* bytes);
 int32_t vs_search_batch_device(vs_store* s, const float* d_queries, uint32_t n_q, uint32_t dim,
                                uint32_t k, const uint64_t* d_mask_words, void* d_workspace,
-                               uint64_t* d_out_keys, void* hip_stream);
+                               uint64_t workspace_bytes, uint64_t* d_out_keys, void* hip_stream);
 
 /* Merges `n_lists` ascending key lists of `k` entries each (list i at
  * d_keys + i * k; e.g. the all-gathered shard results) into the global top-k

@@ -67,10 +67,10 @@ SIGNATURES = {
     "vs_mask_fits": [_vp, _vp],
     "vs_search_mask": [_vp, _f32p, _u32, _u32, _vp, _u32p, _f32p, _u32p],
     "vs_search_workspace_bytes": [_vp, _u32, _u64p],
-    "vs_search_device": [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp],
+    "vs_search_device": [_vp, _vp, _u32, _u32, _vp, _vp, _u64, _vp, _vp],
     "vs_search_device_noalloc": [_vp, _vp, _u32, _u32, _vp, _vp, _vp],
     "vs_search_batch_workspace_bytes": [_vp, _u32, _u64p],
-    "vs_search_batch_device": [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp],
+    "vs_search_batch_device": [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _u64, _vp, _vp],
     "vs_merge_topk_device": [_vp, _vp, _u32, _u32, _i32, _vp, _vp, _vp, _vp],
     "vs_merge_topk_batch_device": [_vp, _vp, _u32, _u64, _u32, _u64, _u32, _i32, _vp, _vp, _vp, _vp],
     "vs_group_unique_id": [_u8p],
@@ -397,17 +397,25 @@ class Store:
         self._ck(lib.vs_search_batch_workspace_bytes(self.handle, k, ctypes.byref(b)))
         return b.value
 
-    def search_batch_device(self, d_queries, n_q, dim, k, d_mask, d_workspace, d_out_keys, stream=0):
+    def search_batch_device(self, d_queries, n_q, dim, k, d_mask, d_workspace, d_out_keys, stream=0,
+                            workspace_bytes=None):
         """vs_search_batch_device: up to 256 queries sharing passes over the rows (bf16 matrix cores,
         8 / 32 f32 queries per pass, 4 binary ones; other stores one scan per query); keys out. Raw
-        device addresses, asynchronous on `stream`."""
+        device addresses, asynchronous on `stream`. workspace_bytes: the size of the buffer behind
+        d_workspace (the library checks it); None = the caller sized it with batch_workspace_bytes(k)
+        for the store as it is now."""
+        if workspace_bytes is None:
+            workspace_bytes = self.batch_workspace_bytes(k)
         self._ck(lib.vs_search_batch_device(self.handle, d_queries, n_q, dim, k, d_mask, d_workspace,
-                                            d_out_keys, stream))
+                                            workspace_bytes, d_out_keys, stream))
 
-    def search_device(self, d_query, dim, k, d_mask, d_workspace, d_out_keys, stream=0):
-        """All arguments are raw device addresses (ints); asynchronous on `stream`."""
-        self._ck(lib.vs_search_device(self.handle, d_query, dim, k, d_mask, d_workspace, d_out_keys,
-                                      stream))
+    def search_device(self, d_query, dim, k, d_mask, d_workspace, d_out_keys, stream=0, workspace_bytes=None):
+        """All arguments are raw device addresses (ints); asynchronous on `stream`. workspace_bytes as in
+        search_batch_device (None = sized with workspace_bytes(k) for the store as it is now)."""
+        if workspace_bytes is None:
+            workspace_bytes = self.workspace_bytes(k)
+        self._ck(lib.vs_search_device(self.handle, d_query, dim, k, d_mask, d_workspace, workspace_bytes,
+                                      d_out_keys, stream))
 
     def search_device_noalloc(self, d_query, dim, k, d_mask, d_out_keys, stream=0):
         """vs_search_device on the library's static scratch: no workspace, no allocation."""

@@ -382,6 +382,77 @@ int32_t run_batch_and_fetch(vs_store* s, const vs::SlabView& v, Workspace* ws, c
     return VS_OK;
 }
 
+// Packs one host query the way the device takes it: f32 as it is, binary stores quantised like the
+// rows (bit j = (q[j] > 0), zero padded to whole vectors).
+void pack_query(const vs_store* s, const float* q, unsigned char* dst, size_t q_bytes) {
+    if (s->dtype == VS_BIN1) {
+        uint64_t* w = reinterpret_cast<uint64_t*>(dst);
+        memset(w, 0, q_bytes);
+        for (uint32_t j = 0; j < s->dim; ++j)
+            if (q[j] > 0.0f) w[j >> 6] |= 1ull << (j & 63);
+    } else {
+        memcpy(dst, q, q_bytes);
+    }
+}
+
+// `n_q` independent single-query searches, host queries and host results, with ONE scan launch, one
+// merge launch and one wait per chunk of queries: query i runs under d_cand_of[i] (device words
+// aligned with the store, nullable) if `d_cand_of` is given, else under d_cand (nullable). No row read
+// is shared, so result i is bit for bit vs_search's.
+int32_t run_queries_and_fetch(vs_store* s, const vs::SlabView& v, Workspace* ws, const float* h_queries,
+                              uint32_t n_q, uint32_t k, const uint64_t* d_cand,
+                              const uint64_t* const* d_cand_of, uint32_t* out_ids, float* out_dist,
+                              uint32_t* out_n) {
+    const vs::ScanTuning t = tuning_of(s->ctx);
+    const bool masked = d_cand != nullptr || d_cand_of != nullptr;
+    const uint32_t blocks = vs::scan_grid_blocks(v, t, masked);
+    const size_t per_query = (size_t)blocks * k * 8;
+    // queries per launch: the partial lists of a chunk stay within 64 MiB
+    size_t chunk_q = (64u << 20) / per_query;
+    chunk_q = chunk_q < 1 ? 1 : chunk_q > 256 ? 256 : chunk_q;
+    if (chunk_q > n_q) chunk_q = n_q;
+    if (int32_t rc = grow(&ws->d_partial, &ws->partial_bytes, chunk_q * per_query)) return rc;
+    const size_t q_bytes = s->dtype == VS_BIN1 ? (size_t)s->row_vecs * 16 : (size_t)s->dim * 4;
+    const size_t q_stride = (q_bytes + 255) / 256 * 256;
+    // one device block and one host block: queries | mask pointers | ids, distances, counts
+    const size_t off_tab = chunk_q * q_stride, off_res = off_tab + (chunk_q * 8 + 255) / 256 * 256;
+    const size_t res_bytes = chunk_q * k * 8 + chunk_q * 4;
+    if (int32_t rc = grow(&ws->d_batch, &ws->batch_bytes, off_res + res_bytes)) return rc;
+    std::vector<unsigned char> up(off_res), down(res_bytes);
+    for (uint32_t at = 0; at < n_q; at += (uint32_t)chunk_q) {
+        const uint32_t m = n_q - at < chunk_q ? n_q - at : (uint32_t)chunk_q;
+        for (uint32_t i = 0; i < m; ++i)
+            pack_query(s, h_queries + (size_t)(at + i) * s->dim, up.data() + i * q_stride, q_bytes);
+        if (d_cand_of) memcpy(up.data() + off_tab, d_cand_of + at, (size_t)m * 8);
+        unsigned char* d_res = ws->d_batch + off_res;
+        uint32_t* d_ids = reinterpret_cast<uint32_t*>(d_res);
+        float* d_dist = reinterpret_cast<float*>(d_res + chunk_q * k * 4);
+        uint32_t* d_n = reinterpret_cast<uint32_t*>(d_res + chunk_q * k * 8);
+        HIP_TRY(hipMemcpyAsync(ws->d_batch, up.data(), off_tab + (d_cand_of ? (size_t)m * 8 : 0), hipMemcpyHostToDevice,
+                               ws->stream));
+        if (int32_t rc = launch_scan_queries(
+                v, t, ws->d_batch, q_stride, m, d_cand,
+                d_cand_of ? reinterpret_cast<const uint64_t* const*>(ws->d_batch + off_tab) : nullptr, k,
+                ws->d_partial, ws->stream))
+            return rc;
+        HIP_TRY(vs::launch_merge_batch(ws->d_partial, blocks, 1, blocks, m, (uint64_t)blocks * k, k, v.metric, nullptr,
+                                       d_ids, d_dist, d_n, ws->stream));
+        HIP_TRY(hipMemcpyAsync(down.data(), d_res, res_bytes, hipMemcpyDeviceToHost, ws->stream));
+        HIP_TRY(hipStreamSynchronize(ws->stream));
+        const uint32_t* h_ids = reinterpret_cast<const uint32_t*>(down.data());
+        const float* h_dist = reinterpret_cast<const float*>(down.data() + chunk_q * k * 4);
+        const uint32_t* h_n = reinterpret_cast<const uint32_t*>(down.data() + chunk_q * k * 8);
+        for (uint32_t i = 0; i < m; ++i) {
+            const uint32_t n = h_n[i];
+            if (n > k) return fail(VS_E_DEVICE, "device returned %u results for k = %u", n, k);
+            memcpy(out_ids + (size_t)(at + i) * k, h_ids + (size_t)i * k, (size_t)n * 4);
+            memcpy(out_dist + (size_t)(at + i) * k, h_dist + (size_t)i * k, (size_t)n * 4);
+            out_n[at + i] = n;
+        }
+    }
+    return VS_OK;
+}
+
 // Several queries under one candidate mask outside the matrix-core path (f32 and binary stores,
 // other metrics, larger k): 32, eight or four queries per pass over the rows where a multi-query
 // scan serves the store, else one scan each; the launches of a chunk are queued back to back on the
@@ -394,10 +465,10 @@ int32_t run_many_and_fetch(vs_store* s, const vs::SlabView& v, Workspace* ws, co
     // several queries share every pass over the rows where one of the multi-query scans serves the store
     const bool shared = shared_pass_serves(v, k);
     const bool shared_bits = vs::scan_hamming_multi_serves(v, k);  // binary rows: four queries per pass
+    if (!shared && !shared_bits)  // (larger k, longer rows): one scan per query, all in one launch
+        return run_queries_and_fetch(s, v, ws, h_queries, n_q, k, d_cand, nullptr, out_ids, out_dist, out_n);
     if (int32_t rc = grow(&ws->d_partial, &ws->partial_bytes,
-                          shared        ? (size_t)shared_pass_partial_bytes(v, k)
-                          : shared_bits ? (size_t)vs::scan_workspace_bytes(v, k) * 4
-                                        : (size_t)vs::scan_workspace_bytes(v, k)))
+                          shared ? (size_t)shared_pass_partial_bytes(v, k) : (size_t)vs::scan_workspace_bytes(v, k) * 4))
         return rc;
     const size_t chunk_q = 64;
     const bool bin = s->dtype == VS_BIN1;
@@ -409,16 +480,7 @@ int32_t run_many_and_fetch(vs_store* s, const vs::SlabView& v, Workspace* ws, co
     for (uint32_t at = 0; at < n_q; at += (uint32_t)chunk_q) {
         const uint32_t m = n_q - at < chunk_q ? n_q - at : (uint32_t)chunk_q;
         for (uint32_t i = 0; i < m; ++i) {
-            const float* q = h_queries + (size_t)(at + i) * s->dim;
-            unsigned char* dst = hq.data() + i * q_stride;
-            if (bin) {  // quantised like the rows: bit j = (q[j] > 0), zero padded to whole vectors
-                uint64_t* w = reinterpret_cast<uint64_t*>(dst);
-                memset(w, 0, q_bytes);
-                for (uint32_t j = 0; j < s->dim; ++j)
-                    if (q[j] > 0.0f) w[j >> 6] |= 1ull << (j & 63);
-            } else {
-                memcpy(dst, q, q_bytes);
-            }
+            pack_query(s, h_queries + (size_t)(at + i) * s->dim, hq.data() + i * q_stride, q_bytes);
         }
         unsigned char* d_res = ws->d_batch + chunk_q * q_stride;
         uint32_t* d_ids = reinterpret_cast<uint32_t*>(d_res);
@@ -430,18 +492,12 @@ int32_t run_many_and_fetch(vs_store* s, const vs::SlabView& v, Workspace* ws, co
                                                  (uint32_t)(q_stride / 4), m, d_cand, k, ws->d_partial, nullptr,
                                                  d_ids, d_dist, d_n, ws->stream))
                 return rc;
-        } else if (shared_bits) {
+        } else {
             for (uint32_t i = 0; i < m; i += 4)
                 HIP_TRY(vs::launch_scan_hamming_multi(v, ws->d_batch + i * q_stride, (uint32_t)(q_stride / 16),
                                                       m - i < 4 ? m - i : 4, d_cand, k, ws->d_partial, nullptr,
                                                       d_ids + (size_t)i * k, d_dist + (size_t)i * k, d_n + i, t,
                                                       ws->stream));
-        } else {
-            for (uint32_t i = 0; i < m; ++i)
-                if (int32_t rc = launch_scan(v, t, ws->d_batch + i * q_stride, d_cand, k, ws->d_partial, nullptr,
-                                             d_ids + (size_t)i * k, d_dist + (size_t)i * k, d_n + i,
-                                             ws->stream))
-                    return rc;
         }
         HIP_TRY(hipMemcpyAsync(hr.data(), d_res, res_bytes, hipMemcpyDeviceToHost, ws->stream));
         HIP_TRY(hipStreamSynchronize(ws->stream));
@@ -792,7 +848,9 @@ void mark_dirty(vs_store* s, uint64_t slot) {
 
 bool visible(const vs_store* s, uint64_t slot) { return (s->h_visible[slot >> 6] >> (slot & 63)) & 1; }
 
-// Makes room for `rows` parked rows (contents kept).
+// Makes room for `rows` parked rows (contents kept). Earlier vs_store_upload_device calls may still
+// be copying parked rows into the old buffer on their callers' streams: those copies are waited for
+// before the buffer is copied and freed.
 int32_t reserve_pending(vs_store* s, size_t rows) {
     if (rows <= s->pending_cap_rows) return VS_OK;
     size_t cap = s->pending_cap_rows ? s->pending_cap_rows * 2 : 1024;
@@ -800,8 +858,13 @@ int32_t reserve_pending(vs_store* s, size_t rows) {
     unsigned char* fresh = nullptr;
     HIP_TRY(hipMalloc(&fresh, cap * s->row_bytes()));
     if (s->d_pending) {
-        const hipError_t e = hipMemcpy(fresh, s->d_pending, s->pending_cap_rows * s->row_bytes(),
-                                       hipMemcpyDeviceToDevice);
+        hipError_t e = hipSuccess;
+        for (auto& kv : s->upload_events) {
+            const hipError_t w = hipEventSynchronize(kv.second);
+            if (w != hipSuccess) e = w;
+        }
+        if (e == hipSuccess)
+            e = hipMemcpy(fresh, s->d_pending, s->pending_cap_rows * s->row_bytes(), hipMemcpyDeviceToDevice);
         if (e != hipSuccess) {
             (void)hipFree(fresh);
             return fail(VS_E_DEVICE, "copying parked rows failed: %s", hipGetErrorString(e));
@@ -811,6 +874,15 @@ int32_t reserve_pending(vs_store* s, size_t rows) {
     s->d_pending = fresh;
     s->pending_cap_rows = cap;
     return VS_OK;
+}
+
+// Forgets the rows parked since there were `n_before` of them (a failed upload: its parked rows
+// have no room, so the next seal must not scatter them).
+void unpark_from(vs_store* s, size_t n_before) {
+    while (s->pending_slots.size() > n_before) {
+        s->pending_of_slot.erase(s->pending_slots.back());
+        s->pending_slots.pop_back();
+    }
 }
 
 // Where the writer puts the row of `slot`: the slab itself while no search can see the slot,
@@ -857,11 +929,15 @@ extern "C" int32_t vs_store_upload(vs_store* s, const uint32_t* docids, const fl
         const size_t row_b = ((size_t)m * s->dim * 4 + 7) / 8 * 8;
         memcpy(ctx->h_stage, rows + at * s->dim, (size_t)m * s->dim * 4);
         uint64_t* dest = reinterpret_cast<uint64_t*>(ctx->h_stage + row_b);
+        const size_t parked_before = s->pending_slots.size();
         for (uint64_t i = 0; i < m; ++i) {
             const uint32_t d = docids[at + i];
             dest[i] = dups && last[d] != at + i ? vs::INGEST_SKIP : route_slot(s, d - s->docid_base);
         }
-        if (int32_t rc = reserve_pending(s, s->pending_slots.size())) return rc;
+        if (int32_t rc = reserve_pending(s, s->pending_slots.size())) {
+            unpark_from(s, parked_before);
+            return rc;
+        }
         HIP_TRY(hipMemcpyAsync(ctx->d_stage, ctx->h_stage, row_b + (size_t)m * 8,
                                hipMemcpyHostToDevice, ctx->upload_stream));
         HIP_TRY(vs::launch_ingest_f32(v, s->d_rows, s->d_pending, reinterpret_cast<const float*>(ctx->d_stage),
@@ -901,8 +977,12 @@ extern "C" int32_t vs_store_upload_device(vs_store* s, uint32_t first_docid,
     } else {
         // rows that replace visible items are parked; copies go run by run
         std::vector<uint64_t> dest(n);
+        const size_t parked_before = s->pending_slots.size();
         for (uint64_t i = 0; i < n; ++i) dest[i] = route_slot(s, slot0 + i);
-        if (int32_t rc = reserve_pending(s, s->pending_slots.size())) return rc;
+        if (int32_t rc = reserve_pending(s, s->pending_slots.size())) {
+            unpark_from(s, parked_before);
+            return rc;
+        }
         for (uint64_t i = 0; i < n;) {
             uint64_t j = i + 1;
             while (j < n && dest[j] == dest[j - 1] + 1) ++j;  // consecutive slots, or consecutive parked rows
@@ -1254,9 +1334,63 @@ extern "C" int32_t vs_search_batch_masks(vs_store* s, const float* queries, uint
         std::vector<float> q;
         std::vector<uint32_t> ids, cnt;
         std::vector<float> dist;
+        auto scatter = [&](const std::vector<uint32_t>& members, size_t from, size_t m) {
+            for (size_t j = 0; j < m; ++j) {
+                const uint32_t i = members[from + j];
+                memcpy(out_ids + (size_t)i * k, ids.data() + j * k, (size_t)cnt[j] * 4);
+                memcpy(out_dist + (size_t)i * k, dist.data() + j * k, (size_t)cnt[j] * 4);
+                out_n[i] = cnt[j];
+            }
+        };
+        auto gather_queries = [&](const std::vector<uint32_t>& members, size_t from, size_t m) {
+            q.resize(m * dim);
+            for (size_t j = 0; j < m; ++j)
+                memcpy(q.data() + j * dim, queries + (size_t)members[from + j] * dim, (size_t)dim * 4);
+            ids.assign(m * k, 0);
+            dist.assign(m * k, 0.0f);
+            cnt.assign(m, 0);
+        };
+        // Queries alone under their filter (a batch of requests with a universe each): ONE scan launch per
+        // chunk takes them all, every query under its own mask. Host words are staged side by side, at most
+        // 256 MiB of them at a time.
+        std::vector<uint32_t> solo;
+        std::vector<Filter> solo_filter;
+        for (auto& kv : groups)
+            if (kv.second.size() == 1) {
+                solo.push_back(kv.second[0]);
+                solo_filter.push_back(kv.first);
+            }
+        const size_t mask_bytes = (size_t)(s->n_slots / 64) * 8;
+        size_t chunk = (256u << 20) / mask_bytes;
+        chunk = chunk < 1 ? 1 : chunk > 256 ? 256 : chunk;
+        for (size_t at = 0; at < solo.size(); at += chunk) {
+            const size_t m = solo.size() - at < chunk ? solo.size() - at : chunk;
+            size_t staged = 0;
+            for (size_t j = 0; j < m; ++j) staged += solo_filter[at + j].words ? 1 : 0;
+            if (staged)
+                if (int32_t rc = grow(&ws->d_mask, &ws->mask_words, staged * mask_bytes)) return rc;
+            std::vector<const uint64_t*> cand_of(m, nullptr);
+            staged = 0;
+            for (size_t j = 0; j < m; ++j) {
+                const Filter& f = solo_filter[at + j];
+                if (f.mask) {
+                    cand_of[j] = f.mask->d_words;
+                } else if (f.words) {
+                    uint64_t* d_words = ws->d_mask + staged++ * (mask_bytes / 8);
+                    if (int32_t rc = copy_dense_mask(s, ws->stream, d_words, f.words, f.n_words)) return rc;
+                    cand_of[j] = d_words;
+                }
+            }
+            gather_queries(solo, at, m);
+            if (int32_t rc = run_queries_and_fetch(s, v, ws, q.data(), (uint32_t)m, k, nullptr, cand_of.data(),
+                                                   ids.data(), dist.data(), cnt.data()))
+                return rc;
+            scatter(solo, at, m);
+        }
         for (auto& kv : groups) {
             const Filter& f = kv.first;
             const std::vector<uint32_t>& members = kv.second;
+            if (members.size() == 1) continue;
             const uint64_t* d_cand = nullptr;
             if (f.mask) {
                 d_cand = f.mask->d_words;
@@ -1264,21 +1398,11 @@ extern "C" int32_t vs_search_batch_masks(vs_store* s, const float* queries, uint
                 if (int32_t rc = stage_dense_mask(s, ws, f.words, f.n_words)) return rc;
                 d_cand = ws->d_mask;
             }
-            const uint32_t m = (uint32_t)members.size();
-            q.resize((size_t)m * dim);
-            for (uint32_t j = 0; j < m; ++j)
-                memcpy(q.data() + (size_t)j * dim, queries + (size_t)members[j] * dim, (size_t)dim * 4);
-            ids.assign((size_t)m * k, 0);
-            dist.assign((size_t)m * k, 0.0f);
-            cnt.assign(m, 0);
-            if (int32_t rc = batch_under_mask(s, v, ws, q.data(), m, k, d_cand, ids.data(), dist.data(), cnt.data()))
+            gather_queries(members, 0, members.size());
+            if (int32_t rc = batch_under_mask(s, v, ws, q.data(), (uint32_t)members.size(), k, d_cand, ids.data(),
+                                              dist.data(), cnt.data()))
                 return rc;
-            for (uint32_t j = 0; j < m; ++j) {
-                const uint32_t i = members[j];
-                memcpy(out_ids + (size_t)i * k, ids.data() + (size_t)j * k, (size_t)cnt[j] * 4);
-                memcpy(out_dist + (size_t)i * k, dist.data() + (size_t)j * k, (size_t)cnt[j] * 4);
-                out_n[i] = cnt[j];
-            }
+            scatter(members, 0, members.size());
         }
         return VS_OK;
     });
@@ -1294,7 +1418,7 @@ extern "C" int32_t vs_search_workspace_bytes(vs_store* s, uint32_t k, uint64_t* 
 }
 
 extern "C" int32_t vs_search_device(vs_store* s, const void* d_query, uint32_t dim, uint32_t k,
-                                    const uint64_t* d_mask_words, void* d_workspace,
+                                    const uint64_t* d_mask_words, void* d_workspace, uint64_t workspace_bytes,
                                     uint64_t* d_out_keys, void* hip_stream) {
     if (int32_t rc = check_store(s)) return rc;
     if (!d_query || !d_workspace || !d_out_keys) return fail(VS_E_INVALID_ARG, "null device buffer");
@@ -1302,9 +1426,14 @@ extern "C" int32_t vs_search_device(vs_store* s, const void* d_query, uint32_t d
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     Snapshot snap;
     snapshot_begin(s, &snap);
-    const int32_t rc = launch_scan(snap.v, tuning_of(s->ctx), d_query, d_mask_words, k,
-                                   static_cast<uint64_t*>(d_workspace), d_out_keys, nullptr, nullptr, nullptr,
-                                   stream);
+    // against the store as registered: a workspace sized before a vs_store_reserve is too small now
+    const uint64_t need = vs::scan_workspace_bytes(snap.v, k);
+    const int32_t rc = workspace_bytes < need
+                           ? fail(VS_E_CAPACITY, "workspace of %llu bytes, the store needs %llu now (vs_search_workspace_bytes)",
+                                  (unsigned long long)workspace_bytes, (unsigned long long)need)
+                           : launch_scan(snap.v, tuning_of(s->ctx), d_query, d_mask_words, k,
+                                         static_cast<uint64_t*>(d_workspace), d_out_keys, nullptr, nullptr, nullptr,
+                                         stream);
     const int32_t rc2 = snapshot_end_async(s, &snap, stream, true);
     return rc ? rc : rc2;
 }
@@ -1412,7 +1541,8 @@ extern "C" int32_t vs_search_batch_workspace_bytes(vs_store* s, uint32_t k, uint
 
 extern "C" int32_t vs_search_batch_device(vs_store* s, const float* d_queries, uint32_t n_q,
                                           uint32_t dim, uint32_t k, const uint64_t* d_mask_words,
-                                          void* d_workspace, uint64_t* d_out_keys, void* hip_stream) {
+                                          void* d_workspace, uint64_t workspace_bytes, uint64_t* d_out_keys,
+                                          void* hip_stream) {
     if (int32_t rc = check_store(s)) return rc;
     if (!d_queries || !d_workspace || !d_out_keys) return fail(VS_E_INVALID_ARG, "null device buffer");
     if (int32_t rc = check_device_search(s, dim, k)) return rc;
@@ -1421,8 +1551,14 @@ extern "C" int32_t vs_search_batch_device(vs_store* s, const float* d_queries, u
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     Snapshot snap;
     snapshot_begin(s, &snap);
-    const int32_t rc = launch_batch(s, snap.v, tuning_of(s->ctx), d_queries, n_q, k, d_mask_words, d_workspace,
-                                    d_out_keys, stream);
+    bool served = false;
+    const uint64_t need = batch_workspace_bytes_for(s, snap.v, k, &served);
+    const int32_t rc = served && workspace_bytes < need
+                           ? fail(VS_E_CAPACITY,
+                                  "workspace of %llu bytes, the store needs %llu now (vs_search_batch_workspace_bytes)",
+                                  (unsigned long long)workspace_bytes, (unsigned long long)need)
+                           : launch_batch(s, snap.v, tuning_of(s->ctx), d_queries, n_q, k, d_mask_words, d_workspace,
+                                          d_out_keys, stream);
     const int32_t rc2 = snapshot_end_async(s, &snap, stream, true);
     return rc ? rc : rc2;
 }

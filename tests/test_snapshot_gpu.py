@@ -244,3 +244,121 @@ def test_one_filter_per_query(gpu_ctx):
         store.destroy_mask(h1)
     finally:
         store.destroy()
+
+
+@pytest.mark.parametrize("dtype_name,dim,k", [("f32", 96, 10), ("f32", 768, 300), ("bin1", 1536, 100)])
+def test_a_filter_of_its_own_for_every_query(gpu_ctx, dtype_name, dim, k):
+    """A batch of requests with a universe each: no two queries share a filter, so every one is a group
+    of its own, and the call scans for all of them in ONE launch, each query under its own mask (host
+    words staged side by side, device masks named in place, one query without a filter). Result i is
+    bit for bit vs_search of query i under filter i."""
+    from search_engine_amd import abi
+    n = 40_000
+    dtype, metric = (abi.VS_BIN1, abi.VS_HAMMING) if dtype_name == "bin1" else (abi.VS_F32, abi.VS_ANGULAR)
+    rows = synthetic_vectors(n, dim, 63)
+    store = gpu_ctx.create_store(706, dim, n, dtype=dtype, metric=metric)
+    handles = []
+    try:
+        store.upload(np.arange(n, dtype=np.uint32), rows)
+        store.seal()
+        queries = synthetic_vectors(9, dim, 64)
+        handles = [store.create_mask(facet_mask(n, p)) for p in (2, 30)]
+        short = facet_mask(n, 60)[: n // 128]  # fewer words than the store has: the rest are no candidates
+        filters = [facet_mask(n, 10), handles[0], None, facet_mask(n, 50), handles[1], short,
+                   facet_mask(n, 100), facet_mask(n, 1), np.zeros(n // 64 + 1, np.uint64)]
+        got = store.search_batch_masks(queries, k, filters)
+        for i, f in enumerate(filters):
+            if f is None or isinstance(f, np.ndarray):
+                want = store.search(queries[i], k, f)
+            else:
+                want = store.search_mask(queries[i], k, f)
+            assert got[i][0].tolist() == want[0].tolist(), i
+            assert got[i][1].tobytes() == want[1].tobytes(), i
+        assert got[8][0].size == 0 and got[2][0].size == k
+    finally:
+        for h in handles:
+            store.destroy_mask(h)
+        store.destroy()
+
+
+def test_parked_rows_survive_the_growth_of_their_buffer(gpu_ctx):
+    """Rows that replace visible items are parked beside the slab; the buffer starts at 1024 rows and is
+    regrown (copy, then free) when an upload needs more. Copies of an earlier vs_store_upload_device may
+    still be queued on the caller's stream at that moment: the growth has to wait for them, or the rows
+    they park are lost and the seal scatters garbage."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n, dim, k = 4096, 64, 5
+    rows_a = synthetic_vectors(n, dim, 81)
+    rows_b = synthetic_vectors(n, dim, 82)
+    store = gpu_ctx.create_store(707, dim, n)
+    try:
+        store.upload(np.arange(n, dtype=np.uint32), rows_a)
+        store.seal()
+        side = torch.cuda.Stream(device=dev)
+        d_b = torch.from_numpy(rows_b).to(dev)
+        busy = torch.randn(4096, 4096, device=dev)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            for _ in range(40):  # the copies below queue up behind this
+                busy = busy @ busy * 1e-4
+            store.upload_device(0, d_b[:700].data_ptr(), 700, side.cuda_stream)            # parks 700 rows
+            store.upload_device(700, d_b[700:2500].data_ptr(), 1800, side.cuda_stream)      # 2500 > 1024: regrown
+            store.upload_device(2500, d_b[2500:3000].data_ptr(), 500, side.cuda_stream)     # 3000 > 2048: again
+        # until the seal, searches still see generation A
+        got, _ = store.search(rows_a[10], k)
+        assert got[0] == 10
+        store.seal()
+        torch.cuda.synchronize()
+        for d in (0, 5, 699, 700, 1023, 1024, 2047, 2048, 2499, 2500, 2999):
+            assert store.item_vector(d).tobytes() == rows_b[d].tobytes(), d
+            got, dist = store.search(rows_b[d], k)
+            assert got[0] == d and dist[0] < 1e-6
+        for d in (3000, 4095):
+            assert store.item_vector(d).tobytes() == rows_a[d].tobytes(), d
+    finally:
+        store.destroy()
+
+
+def test_a_workspace_sized_before_the_store_grew_is_refused(gpu_ctx):
+    """Device-API searches take the size of their workspace and check it against the store as it is
+    now: the batched scan's workspace grows with the store, so one sized before vs_store_reserve would
+    be overrun."""
+    import torch
+    from search_engine_amd import abi
+    dev = torch.device("cuda", 0)
+    dim, k, n_q = 256, 10, 32
+    store = gpu_ctx.create_store(708, dim, 100_000, dtype=abi.VS_BF16)
+    try:
+        rows = synthetic_vectors(100_000, dim, 83)
+        store.upload(np.arange(100_000, dtype=np.uint32), rows)
+        store.seal()
+        before = store.batch_workspace_bytes(k)
+        ws = torch.empty(before, dtype=torch.uint8, device=dev)
+        d_q = torch.from_numpy(synthetic_vectors(n_q, dim, 84)).to(dev)
+        keys = torch.zeros(n_q * k, dtype=torch.int64, device=dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        store.search_batch_device(d_q.data_ptr(), n_q, dim, k, 0, ws.data_ptr(), keys.data_ptr(), stream,
+                                  workspace_bytes=before)
+        torch.cuda.synchronize()
+        want = keys.clone()
+        store.reserve(3_000_000)
+        after = store.batch_workspace_bytes(k)
+        assert after > before
+        with pytest.raises(abi.VsError) as err:
+            store.search_batch_device(d_q.data_ptr(), n_q, dim, k, 0, ws.data_ptr(), keys.data_ptr(), stream,
+                                      workspace_bytes=before)
+        assert err.value.code == abi.VS_E_CAPACITY
+        ws = torch.empty(after, dtype=torch.uint8, device=dev)
+        keys.zero_()
+        store.search_batch_device(d_q.data_ptr(), n_q, dim, k, 0, ws.data_ptr(), keys.data_ptr(), stream,
+                                  workspace_bytes=after)
+        torch.cuda.synchronize()
+        assert keys.cpu().tolist() == want.cpu().tolist()
+        # the single-query entry checks its size too
+        one = torch.zeros(k, dtype=torch.int64, device=dev)
+        with pytest.raises(abi.VsError) as err:
+            store.search_device(d_q.data_ptr(), dim, k, 0, ws.data_ptr(), one.data_ptr(), stream, workspace_bytes=4096)
+        assert err.value.code == abi.VS_E_CAPACITY
+    finally:
+        store.destroy()
