@@ -170,10 +170,12 @@ int32_t vs_store_writer_len(vs_store* s, uint64_t* n_items);
  * uploads every ITEM LEAF into the store whose index is the key's
  * `(embedder_id << 8) | k` (stores must have been created; the write path's
  * "vectors packed in the first writers" layout, typed_chunk.rs:597-607, is
- * thereby taken over as it is on disk). Tree nodes and metadata are skipped and
- * counted in *n_other_nodes: the exhaustive scan needs no forest. Leaves of an
- * index without a store are counted in *n_unrouted. A leaf whose dimension
- * differs from its store's is VS_E_DIM_MISMATCH, anything malformed VS_E_FORMAT.
+ * thereby taken over as it is on disk). Tree nodes, metadata and keys of a mode
+ * this layout does not know are skipped and counted in *n_other_nodes: the
+ * exhaustive scan needs no forest. Leaves of an index without a store are counted
+ * in *n_unrouted. A leaf whose dimension differs from its store's is
+ * VS_E_DIM_MISMATCH, anything malformed VS_E_FORMAT; every pair is checked before
+ * the first row is uploaded, so a failed call leaves the stores as they were.
  * Follow with vs_store_seal on the stores touched (arroy: build). arroy 0.2.0's
  * node layout is restated from the published crate and unverified here (the
  * crate is not in the reference tree):
@@ -184,7 +186,7 @@ int32_t vs_store_writer_len(vs_store* s, uint64_t* n_items);
 int32_t vs_ingest_arroy_items(vs_ctx* ctx, const uint8_t* const* keys, const size_t* key_lens,
                               const uint8_t* const* values, const size_t* value_lens, uint64_t n,
                               uint64_t* n_items, uint64_t* n_other_nodes, uint64_t* n_unrouted);
-/* The key layout alone (mode: 0 item, 1 tree, 2 metadata). */
+/* The key layout alone (mode: 0 item, 1 tree, 2 metadata; other values are handed back as they are). */
 int32_t vs_arroy_parse_key(const uint8_t* key, size_t len, uint16_t* index, uint8_t* mode,
                            uint32_t* item);
 /* Writes the 7-byte key and the leaf bytes of one item in the layout above
@@ -240,6 +242,37 @@ int32_t vs_mask_fits(vs_store* s, const vs_mask* m);
 /* vs_search with the candidates of `mask` (NULL = every item). */
 int32_t vs_search_mask(vs_store* s, const float* query, uint32_t dim, uint32_t k, const vs_mask* mask,
                        uint32_t* out_ids, float* out_dist, uint32_t* out_n);
+
+/* One query against EVERY vector store of an embedder in one call: replaces the
+ * whole store loop of VectorSort::fill_buffer
+ * (src/search/ranking/vector_sort.rs:55-78), which opens the readers
+ * `(embedder_index << 8) | k` for k = 0, 1, .. until one is missing
+ * (MissingMetadata), calls nns_by_vector(target, limit, None, candidates) on each
+ * and sorts the concatenated lists by distance. Here the stores
+ * store_index_base | 0, | 1, .. (low byte of store_index_base 0) are taken up to
+ * the first that does not exist or was never sealed; the filter crosses to the
+ * device ONCE (the reference passes the same `candidates` to every reader), every
+ * store's scan is queued on one stream, and there is one wait.
+ *   filter: at most one of mask_words (as vs_search), roaring_bytes (as
+ *           vs_search_roaring), mask (as vs_search_mask: made for one of these
+ *           stores; the others must start at the same docid and be no larger);
+ *           all three NULL = every item.
+ *   out_*:  out_cap entries each. Every store contributes its own top-k exactly
+ *           as vs_search returns it (at most k entries, duplicates of a docid
+ *           across stores included: a document has a vector in several stores);
+ *           the n_stores lists go out merged, ascending by (distance, docid,
+ *           store), NaN last. out_store[i] = k of the store entry i came from.
+ *           The reference sorts by distance alone with an unstable sort, so its
+ *           order of exact ties is unspecified; this is one of its orders.
+ *   *out_n_stores is set as soon as the stores are counted; if out_cap <
+ *   n_stores * k the call returns VS_E_CAPACITY and the caller may retry with
+ *   room for *out_n_stores * k entries. No store at all: VS_OK, *out_n = 0.
+ * Errors as vs_search (VS_E_DIM_MISMATCH if any store's dimension differs). */
+int32_t vs_search_stores(vs_ctx* ctx, uint16_t store_index_base, const float* query, uint32_t dim,
+                         uint32_t k, const uint64_t* mask_words, uint64_t n_mask_words,
+                         const uint8_t* roaring_bytes, size_t roaring_len, const vs_mask* mask,
+                         uint32_t* out_ids, float* out_dist, uint8_t* out_store, uint32_t out_cap,
+                         uint32_t* out_n, uint32_t* out_n_stores);
 
 /* `n_q` queries against one shared candidate mask. out_ids / out_dist hold
  * n_q * k entries (query i at offset i * k), out_n holds n_q counts. On a

@@ -66,6 +66,8 @@ SIGNATURES = {
     "vs_mask_destroy": [_vp],
     "vs_mask_fits": [_vp, _vp],
     "vs_search_mask": [_vp, _f32p, _u32, _u32, _vp, _u32p, _f32p, _u32p],
+    "vs_search_stores": [_vp, ctypes.c_uint16, _f32p, _u32, _u32, _u64p, _u64, _u8p, _sz, _vp, _u32p, _f32p, _u8p,
+                         _u32, _u32p, _u32p],
     "vs_search_workspace_bytes": [_vp, _u32, _u64p],
     "vs_search_device": [_vp, _vp, _u32, _u32, _vp, _vp, _u64, _vp, _vp],
     "vs_search_device_noalloc": [_vp, _vp, _u32, _u32, _vp, _vp, _vp],
@@ -191,6 +193,27 @@ class Context:
         _check(lib.vs_ingest_arroy_items(self.handle, keys, klen, vals, vlen, n, ctypes.byref(a), ctypes.byref(b),
                                          ctypes.byref(c)), self.handle)
         return a.value, b.value, c.value
+
+    def search_stores(self, index_base, query, k, mask=None, roaring_bytes=None, mask_handle=None, cap=None):
+        """vs_search_stores: one query against every store index_base | 0, | 1, .. under one filter
+        (dense u64 words, a serialised RoaringBitmap, or a handle from Store.create_mask; none = every
+        item). Returns (ids, distances, store numbers, n_stores), entries ascending by (distance,
+        docid, store). cap: entries of the output buffers (default: room for 256 stores)."""
+        query = np.ascontiguousarray(query, np.float32)
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, np.uint64)
+        cap = 256 * max(k, 1) if cap is None else cap
+        ids, dist, src = np.zeros(max(cap, 1), np.uint32), np.zeros(max(cap, 1), np.float32), np.zeros(max(cap, 1), np.uint8)
+        n, n_stores = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        if roaring_bytes is not None:
+            keep, rp = _bytes_ptr(roaring_bytes)
+        else:
+            keep, rp = None, None
+        _check(lib.vs_search_stores(self.handle, index_base, _ptr(query, _f32p), query.size, k, _ptr(mask, _u64p),
+                                    0 if mask is None else mask.size, rp, 0 if roaring_bytes is None else len(roaring_bytes),
+                                    mask_handle, _ptr(ids, _u32p), _ptr(dist, _f32p), _ptr(src, _u8p), cap,
+                                    ctypes.byref(n), ctypes.byref(n_stores)), self.handle)
+        return ids[: n.value].copy(), dist[: n.value].copy(), src[: n.value].copy(), n_stores.value
 
     def merge_topk_device(self, d_keys, n_lists, k, metric, d_ids, d_dist, d_n, stream=0):
         _check(lib.vs_merge_topk_device(self.handle, d_keys, n_lists, k, metric, d_ids, d_dist, d_n,

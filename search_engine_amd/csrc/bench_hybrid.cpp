@@ -5,7 +5,13 @@
 // the candidate-mask upload over PCIe, the scan, the result download and the CPU-side
 // ranking-rule / merge logic. Prints one JSON line per pass rate.
 //
-//   bench_hybrid [docs=1000000] [dim=768] [queries=200]
+//   bench_hybrid [docs=1000000] [dim=768] [queries=200] [stores=1]
+//
+// stores > 1: documents with several vectors. Store j >= 1 of the embedder holds a vector for every
+// 16^j-th document ("vectors packed in the first writers", typed_chunk.rs:597-607), and the host
+// mirror's fill_buffer searches all stores in one vs_search_stores call (VS_MIRROR_STORE_LOOP=1 in
+// the environment: reader by reader, as the reference's loop does). The bare vs_search / vs_search_mask
+// columns stay single calls on store 0.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -49,30 +55,39 @@ int main(int argc, char** argv) {
     const uint64_t docs = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 1000000;
     const uint32_t dim = argc > 2 ? (uint32_t)std::atoi(argv[2]) : 768;
     const int n_queries = argc > 3 ? std::atoi(argv[3]) : 200;
+    const int n_stores = argc > 4 ? std::atoi(argv[4]) : 1;
     const uint8_t category = 1;
+    if (n_stores < 1 || n_stores > 8) {
+        std::fprintf(stderr, "stores must be 1..8\n");
+        return 1;
+    }
 
     vs_ctx* ctx = nullptr;
     CHECK(vs_init(0, &ctx));
-    vs_store* store = nullptr;
-    CHECK(vs_store_create(ctx, (uint16_t)(category << 8), dim, VS_F32, VS_ANGULAR, 0, docs, &store));
-    {
+    std::vector<vs_store*> stores((size_t)n_stores, nullptr);
+    for (int j = 0; j < n_stores; ++j) {
+        uint64_t every = 1;
+        for (int i = 0; i < j; ++i) every *= 16;
+        CHECK(vs_store_create(ctx, (uint16_t)((category << 8) | j), dim, VS_F32, VS_ANGULAR, 0, docs, &stores[j]));
         const uint64_t chunk = 1 << 16;
         const unsigned n_threads = 16;
         std::vector<float> rows(chunk * n_threads * dim);
         std::vector<uint32_t> ids(chunk * n_threads);
-        for (uint64_t lo = 0; lo < docs; lo += chunk * n_threads) {
-            const uint64_t n = std::min<uint64_t>(chunk * n_threads, docs - lo);
+        const uint64_t items = (docs + every - 1) / every;  // item i is document i * every
+        for (uint64_t lo = 0; lo < items; lo += chunk * n_threads) {
+            const uint64_t n = std::min<uint64_t>(chunk * n_threads, items - lo);
             std::vector<std::thread> pool;
             for (unsigned t = 0; t < n_threads; ++t) {
                 const uint64_t a = std::min<uint64_t>(t * chunk, n), b = std::min<uint64_t>((t + 1) * chunk, n);
-                if (a < b) pool.emplace_back(fill_rows, rows.data() + a * dim, lo + a, b - a, dim);
+                if (a < b) pool.emplace_back(fill_rows, rows.data() + a * dim, lo + a + (uint64_t)j * 0x01000000u, b - a, dim);
             }
             for (auto& th : pool) th.join();
-            for (uint64_t i = 0; i < n; ++i) ids[i] = (uint32_t)(lo + i);
-            CHECK(vs_store_upload(store, ids.data(), rows.data(), n));
+            for (uint64_t i = 0; i < n; ++i) ids[i] = (uint32_t)((lo + i) * every);
+            CHECK(vs_store_upload(stores[j], ids.data(), rows.data(), n));
         }
+        CHECK(vs_store_seal(stores[j]));
     }
-    CHECK(vs_store_seal(store));
+    vs_store* store = stores[0];
 
     std::vector<DocumentId> all(docs);
     for (uint64_t i = 0; i < docs; ++i) all[i] = (DocumentId)i;
@@ -155,19 +170,20 @@ int main(int argc, char** argv) {
                 if (i >= 0) secs[mode] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             }
         }
-        std::printf("{\"workload\": \"hybrid, semanticRatio 0.5, %llu docs x %u f32, top-%llu, facet pass rate %d%%\", "
+        std::printf("{\"workload\": \"hybrid, semanticRatio 0.5, %llu docs x %u f32, top-%llu, facet pass rate %d%%\", \"stores\": %d, \"store_loop\": \"%s\", "
                     "\"vector_search_qps\": %.1f, \"vector_search_ms\": %.4f, \"hybrid_qps\": %.1f, \"hybrid_ms\": %.4f, "
                     "\"bare_vs_search_ms\": %.4f, \"vs_search_mask_ms\": %.4f, \"hybrid_fresh_universe_ms\": %.4f, "
                     "\"hybrid_over_vs_search_mask\": %.3f, \"hybrid_fresh_over_bare_vs_search\": %.3f, "
                     "\"queries\": %d, \"universe\": %zu, \"hits\": %llu}\n",
-                    (unsigned long long)docs, dim, (unsigned long long)limit, pass, n_queries / secs[0],
+                    (unsigned long long)docs, dim, (unsigned long long)limit, pass, n_stores,
+                    std::getenv("VS_MIRROR_STORE_LOOP") ? "reader by reader" : "vs_search_stores", n_queries / secs[0],
                     1e3 * secs[0] / n_queries, n_queries / secs[1], 1e3 * secs[1] / n_queries, 1e3 * secs[2] / n_queries, 1e3 * secs[3] / n_queries, 1e3 * secs[4] / n_queries, secs[1] / secs[3],
                     secs[4] / secs[2], n_queries, u.size(),
                     (unsigned long long)hits);
         std::fflush(stdout);
         CHECK(vs_mask_destroy(kept));
     }
-    CHECK(vs_store_destroy(store));
+    for (vs_store* st : stores) CHECK(vs_store_destroy(st));
     CHECK(vs_shutdown(ctx));
     return 0;
 }

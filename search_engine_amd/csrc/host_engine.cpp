@@ -2,6 +2,8 @@
 // host_engine.h for the map onto the reference's files. CPU control flow only.
 #include "host_engine.h"
 
+#include <cstdlib>
+
 #include <algorithm>
 #include <charconv>
 #include <cmath>
@@ -605,14 +607,51 @@ std::string last_error(vs_ctx* ctx) {
 // universe that never comes back) is sent along with its search; one that comes back (a refill of
 // the same request, the next request under the same facet filter) is uploaded once more, into a
 // vs_mask, and every later search names that mask instead of sending N / 8 bytes again.
+// The slot is shared by every copy of a universe's words and by every thread searching under them;
+// a search holds its own reference to the mask for as long as it runs, so a thread that finds the
+// mask outdated (the store was given more room) and replaces it never frees words another thread's
+// scan is still reading.
 struct DeviceMaskSlot {
     std::mutex mu;
     uint32_t searches = 0;
-    vs_mask* mask = nullptr;
-    ~DeviceMaskSlot() {
-        if (mask) vs_mask_destroy(mask);
-    }
+    std::shared_ptr<vs_mask> mask;
 };
+
+// The device copy of `candidates` for `store`, or null: send the words with the search. Stores of
+// one context never share an address while both live, so the store pointer names the slot; a mask
+// that no longer fits its store (the store was given more room, or its address has been reused) is
+// dropped and made again.
+std::shared_ptr<vs_mask> kept_mask(vs_store* store, const DocSet& candidates) {
+    std::shared_ptr<void> held = candidates.attachment(store);
+    if (!held) {
+        held = std::make_shared<DeviceMaskSlot>();
+        candidates.attach(store, held);
+    }
+    DeviceMaskSlot& slot = *static_cast<DeviceMaskSlot*>(held.get());
+    std::lock_guard<std::mutex> g(slot.mu);
+    if (slot.mask && !vs_mask_fits(store, slot.mask.get())) slot.mask.reset();
+    if (!slot.mask && slot.searches++ >= 1) {
+        static const uint64_t none = 0;
+        const std::vector<uint64_t>& w = candidates.words();
+        vs_mask* made = nullptr;
+        // (no room on the device: the plain search reports what is wrong)
+        if (vs_mask_create(store, w.empty() ? &none : w.data(), w.size(), &made) == VS_OK)
+            slot.mask = std::shared_ptr<vs_mask>(made, [](vs_mask* m) { vs_mask_destroy(m); });
+    }
+    return slot.mask;
+}
+
+void check_vs(vs_ctx* ctx, int32_t rc) {
+    if (rc == VS_E_DIM_MISMATCH) {
+        uint32_t e = 0, r = 0;
+        vs_last_dim_mismatch(ctx, &e, &r);
+        throw Error(Error::InvalidVectorDimensions,
+                    "Invalid vector dimensions: expected: `" + std::to_string(e) + "`, found: `" + std::to_string(r) +
+                        "`.",
+                    e, r);
+    }
+    if (rc != VS_OK) throw Error(Error::ArroyError, last_error(ctx));
+}
 
 class GpuReader : public Reader {
    public:
@@ -625,8 +664,8 @@ class GpuReader : public Reader {
         std::vector<float> dist(count ? count : 1);
         uint32_t n = 0;
         int32_t rc;
-        if (const vs_mask* mask = kept_mask(candidates)) {
-            rc = vs_search_mask(store_, target.data(), (uint32_t)target.size(), (uint32_t)count, mask, ids.data(),
+        if (const std::shared_ptr<vs_mask> mask = kept_mask(store_, candidates)) {
+            rc = vs_search_mask(store_, target.data(), (uint32_t)target.size(), (uint32_t)count, mask.get(), ids.data(),
                                 dist.data(), &n);
         } else {
             static const uint64_t none = 0;
@@ -657,8 +696,8 @@ class GpuReader : public Reader {
         std::vector<uint32_t> ids(n_q * kk), n(n_q, 0);
         std::vector<float> dist(n_q * kk);
         int32_t rc;
-        if (const vs_mask* mask = kept_mask(candidates)) {
-            const std::vector<const vs_mask*> masks(n_q, mask);  // one filter: the queries share passes
+        if (const std::shared_ptr<vs_mask> held = kept_mask(store_, candidates)) {
+            const std::vector<const vs_mask*> masks(n_q, held.get());  // one filter: the queries share passes
             rc = vs_search_batch_masks(store_, flat.data(), (uint32_t)n_q, (uint32_t)dim, (uint32_t)count, nullptr,
                                        nullptr, masks.data(), ids.data(), dist.data(), n.data());
         } else {
@@ -691,11 +730,13 @@ class GpuReader : public Reader {
         // per query: the device copy of its set if one is kept, else the set's words. Queries whose sets
         // share their words (copies of one universe object) name the same pointer and share passes.
         static const uint64_t none = 0;
+        std::vector<std::shared_ptr<vs_mask>> held(n_q);  // (kept alive until the call has returned)
         std::vector<const vs_mask*> masks(n_q, nullptr);
         std::vector<const uint64_t*> words(n_q, nullptr);
         std::vector<uint64_t> n_words(n_q, 0);
         for (size_t i = 0; i < n_q; ++i) {
-            masks[i] = kept_mask(*candidates[i]);
+            held[i] = kept_mask(store_, *candidates[i]);
+            masks[i] = held[i].get();
             const std::vector<uint64_t>& w = candidates[i]->words();
             words[i] = w.empty() ? &none : w.data();  // an empty set is an empty mask, not "no filter"
             n_words[i] = w.empty() ? 1 : w.size();
@@ -710,41 +751,7 @@ class GpuReader : public Reader {
     }
 
    private:
-    void check(int32_t rc) {
-        if (rc == VS_E_DIM_MISMATCH) {
-            uint32_t e = 0, r = 0;
-            vs_last_dim_mismatch(ctx_, &e, &r);
-            throw Error(Error::InvalidVectorDimensions,
-                        "Invalid vector dimensions: expected: `" + std::to_string(e) + "`, found: `" +
-                            std::to_string(r) + "`.",
-                        e, r);
-        }
-        if (rc != VS_OK) throw Error(Error::ArroyError, last_error(ctx_));
-    }
-    // The device copy of `candidates` for this store, or nullptr: send the words with the search.
-    // Stores of one context never share an address while both live, so the store pointer names
-    // the slot; a mask that no longer fits its store (the store was given more room, or its
-    // address has been reused) is dropped and made again.
-    const vs_mask* kept_mask(const DocSet& candidates) {
-        std::shared_ptr<void> held = candidates.attachment(store_);
-        if (!held) {
-            held = std::make_shared<DeviceMaskSlot>();
-            candidates.attach(store_, held);
-        }
-        DeviceMaskSlot& slot = *static_cast<DeviceMaskSlot*>(held.get());
-        std::lock_guard<std::mutex> g(slot.mu);
-        if (slot.mask && !vs_mask_fits(store_, slot.mask)) {
-            vs_mask_destroy(slot.mask);
-            slot.mask = nullptr;
-        }
-        if (!slot.mask && slot.searches++ >= 1) {
-            static const uint64_t none = 0;
-            const std::vector<uint64_t>& w = candidates.words();
-            if (vs_mask_create(store_, w.empty() ? &none : w.data(), w.size(), &slot.mask) != VS_OK)
-                slot.mask = nullptr;  // no room on the device: the plain search reports what is wrong
-        }
-        return slot.mask;
-    }
+    void check(int32_t rc) { check_vs(ctx_, rc); }
     vs_ctx* ctx_;
     vs_store* store_;
 };
@@ -776,6 +783,48 @@ std::unique_ptr<Reader> GpuContext::vector_reader(uint16_t index) {
     if (rc == VS_E_NO_STORE) return nullptr;  // MissingMetadata
     if (rc != VS_OK) throw Error(Error::ArroyError, last_error(ctx_));
     return std::unique_ptr<Reader>(new GpuReader(ctx_, store));
+}
+
+std::optional<std::vector<std::vector<std::pair<DocumentId, float>>>> GpuContext::nns_all_stores(
+    uint8_t embedder_index, const std::vector<float>& target, size_t count, const DocSet& candidates) {
+    static const bool reader_by_reader = getenv("VS_MIRROR_STORE_LOOP") != nullptr;  // measurement switch
+    if (reader_by_reader) return std::nullopt;
+    std::vector<std::vector<std::pair<DocumentId, float>>> per_store;
+    const uint16_t base = (uint16_t)((uint16_t)embedder_index << 8);
+    vs_store* first = nullptr;
+    const int32_t opened = vs_store_open(ctx_, base, &first);
+    if (opened == VS_E_NO_STORE) return per_store;  // MissingMetadata for k = 0: no reader, no result
+    check_vs(ctx_, opened);
+    if (count > VS_MAX_K) throw Error(Error::ArroyError, "limit " + std::to_string(count) + " exceeds VS_MAX_K");
+    // the universe's device copy, kept under the first store: it serves every store that starts at the
+    // same docid and is no larger; otherwise (and the first time a universe is seen) the words go along
+    const std::shared_ptr<vs_mask> held = kept_mask(first, candidates);
+    static const uint64_t none = 0;
+    const std::vector<uint64_t>& w = candidates.words();
+    uint32_t n = 0, n_stores = 0;
+    std::vector<uint32_t> ids;
+    std::vector<float> dist;
+    std::vector<uint8_t> from;
+    auto search = [&](const vs_mask* mask, size_t cap) {
+        ids.resize(cap ? cap : 1);
+        dist.resize(cap ? cap : 1);
+        from.resize(cap ? cap : 1);
+        // an empty candidate set is an empty mask, not "no filter"
+        return vs_search_stores(ctx_, base, target.data(), (uint32_t)target.size(), (uint32_t)count,
+                                mask ? nullptr : (w.empty() ? &none : w.data()), mask ? 0 : w.size(), nullptr, 0, mask,
+                                ids.data(), dist.data(), from.data(), (uint32_t)cap, &n, &n_stores);
+    };
+    const vs_mask* mask = held.get();
+    int32_t rc = search(mask, count * 4);
+    if (rc == VS_E_INVALID_ARG && mask) {  // the mask does not cover some store: send the words
+        mask = nullptr;
+        rc = search(mask, count * 4);
+    }
+    if (rc == VS_E_CAPACITY) rc = search(mask, count * (size_t)n_stores);  // more than four stores
+    check_vs(ctx_, rc);
+    per_store.resize(n_stores);
+    for (uint32_t i = 0; i < n; ++i) per_store[from[i]].emplace_back(ids[i], dist[i]);
+    return per_store;
 }
 
 // ---- VectorSort (src/search/ranking/vector_sort.rs) ------------------------------------------------------
@@ -829,6 +878,11 @@ void VectorSort::fill_buffer() {
         candidates_ -= emitted_;
         emitted_ = DocSet();
         emitted_from_live_ = 0;
+    }
+    // one call for every store of the embedder where the context has one, else reader by reader
+    if (auto all = ctx_.nns_all_stores(embedder_index_, target_, limit_, live_)) {
+        set_cache(std::move(*all));
+        return;
     }
     std::vector<std::vector<std::pair<DocumentId, float>>> per_store;
     for (auto& reader : open_readers(ctx_, embedder_index_))

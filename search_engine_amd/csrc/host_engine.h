@@ -224,6 +224,15 @@ struct Context {
     virtual uint8_t embedder_category_id(const std::string& name) = 0;       // context.rs:59
     // nullptr plays arroy::Error::MissingMetadata ("store k does not exist")
     virtual std::unique_ptr<Reader> vector_reader(uint16_t index) = 0;       // context.rs:60
+    // The whole store loop of VectorSort::fill_buffer (vector_sort.rs:55-78) as one call: result k =
+    // nns_by_vector(target, count, candidates) of the reader (embedder_index << 8) | k, for k = 0.. up
+    // to the first missing store. No counterpart in the reference's trait: a context that has no such
+    // call returns nullopt and the caller opens the readers one by one.
+    virtual std::optional<std::vector<std::vector<std::pair<DocumentId, float>>>> nns_all_stores(
+        uint8_t /*embedder_index*/, const std::vector<float>& /*target*/, size_t /*count*/,
+        const DocSet& /*candidates*/) {
+        return std::nullopt;
+    }
 };
 
 // Context over libvs_amd.so: vector_reader = vs_store_open, nns_by_vector = vs_search.
@@ -234,6 +243,9 @@ class GpuContext : public Context {
     DocSet all_docids() override { return docs_; }
     uint8_t embedder_category_id(const std::string& name) override;
     std::unique_ptr<Reader> vector_reader(uint16_t index) override;
+    // vs_search_stores: the filter crosses to the device once, one wait for all stores
+    std::optional<std::vector<std::vector<std::pair<DocumentId, float>>>> nns_all_stores(
+        uint8_t embedder_index, const std::vector<float>& target, size_t count, const DocSet& candidates) override;
 
    private:
     vs_ctx* ctx_;

@@ -91,32 +91,7 @@ __device__ __forceinline__ uint64_t make_key(uint32_t ordered_distance, uint32_t
 
 // ---- per-wave sorted list in LDS ---------------------------------------------
 
-// `list` holds `k` keys ascending (KEY_NONE = empty slot) and belongs to ONE
-// wave. Inserts the wave-uniform `key`, which the caller has checked to be
-// smaller than list[k-1]; the last entry drops out. Returns the new list[k-1].
-__device__ __forceinline__ uint64_t list_insert(uint64_t* list, int k, uint64_t key,
-                                                int lane) {
-    int pos = 0;
-    for (int base = 0; base < k; base += 64) {
-        const int i = base + lane;
-        const bool lt = (i < k) && (list[i] < key);
-        pos += __popcll(__ballot(lt));
-    }
-    // shift [pos, k-1) up by one, top chunk first so nothing is overwritten
-    // before it has been read
-    for (int base = ((k - 1) >> 6) << 6; base >= 0 && base + 63 > pos; base -= 64) {
-        const int i = base + lane;
-        const bool mv = (i < k) && (i > pos);
-        uint64_t v = 0;
-        if (mv) v = list[i - 1];
-        wave_lds_fence();
-        if (mv) list[i] = v;
-        wave_lds_fence();
-    }
-    if (lane == 0) list[pos] = key;
-    wave_lds_fence();
-    return uniform_u64(list[k - 1]);
-}
+// (the merge of a sorted batch into an LDS list is WaveTopK::merge_parked_lds, below)
 
 // lane i receives lane i-1's value (lane 0 receives `fill`): DPP wave_shr:1
 __device__ __forceinline__ uint64_t wave_shift_up_u64(uint64_t v, uint64_t fill) {
@@ -165,16 +140,84 @@ __device__ __forceinline__ void bitonic_sort128(uint64_t& lo, uint64_t& hi, int 
     bitonic_merge128(lo, hi, lane);  // lo ascending, hi descending: bitonic
 }
 
+// The n_parked keys of `parked` (a wave's 128-entry buffer in LDS) merged into the wave's ascending
+// LDS list of k keys, in place; returns the list's new last entry. The batch is sorted in registers
+// (entry `lane` and entry 64 + lane) and goes back to the buffer; every key's place in the merged list
+// is its own index plus the number of keys of the OTHER sequence below it (keys are distinct: they
+// carry the docid), found by binary search: each lane places two parked keys (11 probes of the list)
+// and, 256 list entries at a time from the top down, four list entries (8 probes of the sorted batch).
+// Entries only move up, and a group is read completely before any of it is written, so the list is
+// rewritten where it lies. About 20 cycles per parked key at k = 1000, against some 1 600 for an insert
+// that shifts the list. Not inlined: one copy per kernel, entered once per 128 candidates or so.
+__device__ __attribute__((noinline)) inline uint64_t merge_parked_into_lds_list(uint64_t* lds, uint64_t* parked,
+                                                                                uint32_t n_parked, int k) {
+    const int lane = (int)(threadIdx.x & 63);
+    uint64_t a = (uint32_t)lane < n_parked ? parked[lane] : KEY_NONE;
+    uint64_t b = (uint32_t)lane + 64 < n_parked ? parked[lane + 64] : KEY_NONE;
+    wave_lds_fence();
+    bitonic_sort128(a, b, lane);
+    parked[lane] = a;
+    parked[lane + 64] = b;
+    wave_lds_fence();
+    auto below_in_list = [&](uint64_t key) {  // number of list entries < key
+        int pos = 0;
+#pragma unroll
+        for (int s = 512; s >= 1; s >>= 1)
+            if (pos + s - 1 < k && lds[pos + s - 1] < key) pos += s;
+        if (pos < k && lds[pos] < key) ++pos;
+        return pos;
+    };
+    const int pa = lane + below_in_list(a), pb = 64 + lane + below_in_list(b);
+    // list entries below the smallest parked key stay where they are (lane 0 holds the smallest)
+    const int first_base = ((int)uniform_u32((uint32_t)pa) >> 6) << 6;
+    for (int top_base = ((k - 1) >> 6) << 6; top_base >= first_base; top_base -= 256) {
+        uint64_t v[4];
+        int at[4], np[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            at[u] = top_base - 64 * u + lane;
+            const bool have = at[u] >= first_base && at[u] < k;
+            v[u] = have ? lds[at[u]] : KEY_NONE;
+            if (!have) at[u] = k;  // nowhere
+            np[u] = 0;
+        }
+#pragma unroll
+        for (int s = 64; s >= 1; s >>= 1) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (parked[np[u] + s - 1] < v[u]) np[u] += s;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (parked[np[u]] < v[u]) ++np[u];
+        wave_lds_fence();
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (at[u] + np[u] < k && np[u] > 0) lds[at[u] + np[u]] = v[u];
+        wave_lds_fence();
+    }
+    if (pa < k) lds[pa] = a;
+    if (pb < k) lds[pb] = b;
+    wave_lds_fence();
+    return uniform_u64(lds[k - 1]);
+}
+
 // The k smallest keys one wave has seen, ascending. For k <= 128 the list lives in
 // two register pairs (lane i holds the i-th and the (64+i)-th smallest) and an
-// insert is two compares, two ballots and a cross-lane shift; larger k use the
-// LDS list above. `tau` is the k-th smallest so far (KEY_NONE while fewer than k
+// insert is two compares, two ballots and a cross-lane shift. Larger k (a request
+// deep into its pagination: limit = offset + limit, src/search/search.rs:115) keep
+// the list in LDS, and keys are never inserted one at a time there: they are parked
+// in a 128-entry buffer and merged into the list a batch at a time (park_in must
+// have been called). `tau` is the k-th smallest so far (KEY_NONE while fewer than k
 // keys are held): only keys below it may be inserted.
-struct WaveTopK {
+// LDS_LISTS = false: for kernels that only ever run with k <= 128 (no code for the LDS list).
+template <bool LDS_LISTS>
+struct WaveTopKT {
     static constexpr int REG_K = 128;
     uint64_t* lds;  // k entries owned by this wave
     int k, lane;
     bool in_regs;
+    __device__ __forceinline__ bool regs() const { return !LDS_LISTS || in_regs; }
     uint64_t lo, hi;  // entries lane and 64 + lane
     uint64_t tau;
     // Batched insertion (register lists with a larger k, where one insert costs a few hundred cycles
@@ -189,17 +232,21 @@ struct WaveTopK {
         lds = lds_;
         k = k_;
         lane = lane_;
-        in_regs = k_ <= REG_K;
+        in_regs = !LDS_LISTS || k_ <= REG_K;
         lo = hi = KEY_NONE;
         tau = KEY_NONE;
-        if (!in_regs) {
+        parked = nullptr;
+        n_parked = 0;
+        if (!regs()) {
             for (int i = lane; i < k; i += 64) lds[i] = KEY_NONE;
             wave_lds_fence();
         }
     }
+    // whether a list of k entries needs a park buffer (128 keys of LDS per wave) to work at all
+    static __host__ __device__ constexpr bool needs_park_buffer(uint32_t k_) { return k_ > (uint32_t)REG_K; }
     // `key` is wave-uniform and < tau
     __device__ __forceinline__ void insert(uint64_t key) {
-        if (in_regs) {
+        if (regs()) {
             const int pos = __popcll(__ballot(lo < key)) + __popcll(__ballot(hi < key));
             const uint64_t carry = readlane_u64(lo, 63);
             const uint64_t up_lo = wave_shift_up_u64(lo, KEY_NONE);
@@ -210,8 +257,15 @@ struct WaveTopK {
             if (lane + 64 >= k) hi = KEY_NONE;
             tau = k <= 64 ? readlane_u64(lo, k - 1) : readlane_u64(hi, k - 65);
         } else {
-            tau = list_insert(lds, k, key, lane);
+            // parked; the list and tau move at the caller's next make_room()
+            if (lane == 0) parked[n_parked] = key;
+            ++n_parked;
         }
+    }
+    // LDS lists: call before up to `n` insert()s in a row (n <= 64), at a point where few registers
+    // are live: this is where the parked keys are merged into the list (a function call).
+    __device__ __forceinline__ void make_room(uint32_t n) {
+        if (!regs() && n_parked + n > 128) merge_parked();
     }
     __device__ __forceinline__ void park_in(uint64_t* buffer128) {
         parked = buffer128;
@@ -222,14 +276,21 @@ struct WaveTopK {
     __device__ __forceinline__ void park(bool mine, uint64_t key) {
         const uint64_t m = __ballot(mine);
         if (!m) return;
+        if (n_parked > 64) merge_parked();  // (keys parked one at a time by insert() may have filled it further)
         const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
         if (mine) parked[n_parked + below] = key;  // at most 64 parked before, at most 64 new: 128 fit
         n_parked += (uint32_t)__popcll(m);
         wave_lds_fence();
-        if (n_parked > 64) merge_parked();
+        if (regs() && n_parked > 64) merge_parked();  // (LDS lists merge at the next call: fewer, fuller batches)
     }
     __device__ __forceinline__ void merge_parked() {
         if (!n_parked) return;
+        if (!regs()) {
+            wave_lds_fence();
+            tau = merge_parked_into_lds_list(lds, parked, n_parked, k);
+            n_parked = 0;
+            return;
+        }
         uint64_t a = (uint32_t)lane < n_parked ? parked[lane] : KEY_NONE;
         uint64_t b = (uint32_t)lane + 64 < n_parked ? parked[lane + 64] : KEY_NONE;
         wave_lds_fence();
@@ -262,7 +323,8 @@ struct WaveTopK {
     // after this the list can be read from `lds` (by this wave, or by others
     // after a workgroup barrier)
     __device__ __forceinline__ void spill() {
-        if (in_regs) {
+        if (!regs()) merge_parked();
+        if (regs()) {
             if (lane < k) lds[lane] = lo;
             if (lane + 64 < k) lds[lane + 64] = hi;
             wave_lds_fence();
@@ -270,7 +332,7 @@ struct WaveTopK {
     }
     // inserts every entry below tau of another wave's spilled list
     __device__ __forceinline__ void absorb(uint64_t* other) {
-        if (in_regs) {
+        if (regs()) {
             // Two ascending lists A (mine) and B: C[i] = min(A[i], B[127 - i]) holds the 128 smallest
             // of both and is bitonic; one merge phase sorts it. A handful of instructions against
             // one insert per entry.
@@ -283,19 +345,24 @@ struct WaveTopK {
             tau = k <= 64 ? readlane_u64(lo, k - 1) : readlane_u64(hi, k - 65);
             return;
         }
-        for (int j = 0; j < k; ++j) {
-            const uint64_t key = uniform_u64(other[j]);
-            if (key >= tau) break;
-            insert(key);
+        // the other list is ascending: 64 entries at a time while any of them is below tau
+        for (int base = 0; base < k; base += 64) {
+            const uint64_t key = base + lane < k ? other[base + lane] : KEY_NONE;
+            const bool mine = key < tau;
+            if (!__ballot(mine)) break;
+            park(mine, key);
         }
+        merge_parked();
     }
     // i-th smallest for i = base + lane (base a multiple of 64), KEY_NONE for i >= k
     __device__ __forceinline__ uint64_t at_lane(int base) const {
         const int i = base + lane;
         if (i >= k) return KEY_NONE;
-        if (in_regs) return base == 0 ? lo : hi;
+        if (regs()) return base == 0 ? lo : hi;
         return lds[i];
     }
 };
+using WaveTopK = WaveTopKT<true>;
+using WaveTopKRegs = WaveTopKT<false>;
 
 }  // namespace vs

@@ -30,7 +30,7 @@ bool arroy_parse_key(const uint8_t* key, size_t len, uint16_t* index, uint8_t* m
     *index = (uint16_t)((uint16_t)key[0] << 8 | key[1]);
     *mode = key[2];
     *item = (uint32_t)key[3] << 24 | (uint32_t)key[4] << 16 | (uint32_t)key[5] << 8 | key[6];
-    return *mode <= ARROY_MODE_METADATA;
+    return true;  // (a mode this layout does not know is some other node: only item leaves are read)
 }
 
 // The vector of an item leaf: pointer into `value` (unaligned) and its dimension; false if the
@@ -99,16 +99,7 @@ extern "C" int32_t vs_ingest_arroy_items(vs_ctx* ctx, const uint8_t* const* keys
         b.rows.clear();
         return rc;
     };
-    for (uint64_t i = 0; i < n; ++i) {
-        uint16_t index;
-        uint8_t mode;
-        uint32_t item;
-        if (!arroy_parse_key(keys[i], key_lens[i], &index, &mode, &item))
-            return fail(VS_E_FORMAT, "pair %llu: not an arroy key (%zu bytes)", (unsigned long long)i, key_lens[i]);
-        if (mode != ARROY_MODE_ITEM) {  // tree nodes and metadata: the forest is not used by an exhaustive scan
-            ++other;
-            continue;
-        }
+    auto store_of = [&](uint16_t index) -> Batch& {
         auto it = batches.find(index);
         if (it == batches.end()) {
             vs_store* store = nullptr;
@@ -119,11 +110,19 @@ extern "C" int32_t vs_ingest_arroy_items(vs_ctx* ctx, const uint8_t* const* keys
             }
             it = batches.emplace(index, Batch{store, {}, {}}).first;
         }
-        Batch& b = it->second;
-        if (!b.store) {  // an index the host made no store for
-            ++unrouted;
-            continue;
-        }
+        return it->second;
+    };
+    // First every pair is checked, then rows are uploaded: a malformed pair or a leaf of the wrong
+    // dimension fails the call before any store has been touched.
+    for (uint64_t i = 0; i < n; ++i) {
+        uint16_t index;
+        uint8_t mode;
+        uint32_t item;
+        if (!arroy_parse_key(keys[i], key_lens[i], &index, &mode, &item))
+            return fail(VS_E_FORMAT, "pair %llu: not an arroy key (%zu bytes)", (unsigned long long)i, key_lens[i]);
+        if (mode != ARROY_MODE_ITEM) continue;
+        Batch& b = store_of(index);
+        if (!b.store) continue;
         const uint8_t* vec;
         uint32_t dim;
         if (!arroy_parse_leaf(values[i], value_lens[i], &vec, &dim))
@@ -133,6 +132,24 @@ extern "C" int32_t vs_ingest_arroy_items(vs_ctx* ctx, const uint8_t* const* keys
             vsrt::set_dim_mismatch(b.store->dim, dim);
             return fail(VS_E_DIM_MISMATCH, "invalid vector dimensions: expected %u, received %u", b.store->dim, dim);
         }
+    }
+    for (uint64_t i = 0; i < n; ++i) {
+        uint16_t index;
+        uint8_t mode;
+        uint32_t item;
+        (void)arroy_parse_key(keys[i], key_lens[i], &index, &mode, &item);
+        if (mode != ARROY_MODE_ITEM) {  // tree nodes, metadata, modes of other arroy versions: an exhaustive scan uses no forest
+            ++other;
+            continue;
+        }
+        Batch& b = store_of(index);
+        if (!b.store) {  // an index the host made no store for
+            ++unrouted;
+            continue;
+        }
+        const uint8_t* vec;
+        uint32_t dim;
+        (void)arroy_parse_leaf(values[i], value_lens[i], &vec, &dim);
         b.docids.push_back(item);
         const size_t at = b.rows.size();
         b.rows.resize(at + dim);

@@ -95,6 +95,7 @@ struct vs_mask {
     uint64_t* d_words;  // store->n_slots / 64 words, aligned with the store
     uint64_t n_slots;   // of the store when the mask was made (vs_store_reserve outdates it)
     uint64_t store_serial;  // of that store: a later store at the same address is another store
+    uint32_t docid_base;    // of that store: word 0 covers docids docid_base ..
 };
 
 // One arroy index as a row slab.
@@ -208,10 +209,11 @@ int32_t launch_scan(const vs::SlabView& v, const vs::ScanTuning& t, const void* 
                     uint32_t k, uint64_t* d_partial, uint64_t* d_keys, uint32_t* d_ids, float* d_dist,
                     uint32_t* d_n, hipStream_t stream);
 // `n_q` independent single-query scans in one launch (partial lists only; the caller merges):
-// query q at d_queries + q * query_bytes, under d_cand_of[q] (device array, nullable) or d_cand.
+// query q at d_queries + q * query_bytes, under d_cand (nullable) over `v` or as d_jobs[q] says
+// (device array, nullable; `v` is then the largest of the jobs' slabs).
 int32_t launch_scan_queries(const vs::SlabView& v, const vs::ScanTuning& t, const void* d_queries,
                             size_t query_bytes, uint32_t n_q, const uint64_t* d_cand,
-                            const uint64_t* const* d_cand_of, uint32_t k, uint64_t* d_partial, hipStream_t stream);
+                            const vs::ScanJob* d_jobs, uint32_t k, uint64_t* d_partial, hipStream_t stream);
 // The batched device search on an already registered snapshot (vs_search_batch_device's body).
 int32_t launch_batch(vs_store* s, const vs::SlabView& v, const vs::ScanTuning& t, const void* d_queries,
                      uint32_t n_q, uint32_t k, const uint64_t* d_mask_words, void* d_workspace,

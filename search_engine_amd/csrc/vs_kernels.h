@@ -54,20 +54,36 @@ hipError_t launch_scan_float(const SlabView& s, const float* d_query, const uint
                                uint32_t* out_ids, float* out_dist, uint32_t* out_n,
                                const ScanTuning& t, hipStream_t stream);
 
+// One query of a many-query launch that is not searched with the launch's common arguments: its own
+// candidate mask, or another slab altogether (the stores of one embedder: same row shape, element
+// type and metric). rows / norms / present / n_slots / docid_base as in SlabView; cand nullable;
+// query nullable = the launch's d_queries + y * query_stride.
+struct ScanJob {
+    const void* rows;
+    const float* norms;
+    const uint64_t* present;
+    const uint64_t* cand;
+    const void* query;
+    uint64_t n_slots;
+    uint32_t docid_base;
+    uint32_t reserved;
+};
+
 // `n_q` independent single-query scans in ONE launch: a workgroup takes its share of the mask words
 // for one query after the other, so the queries follow each other without a launch's ramp and tail
 // in between. No row read is shared; query q's partial lists (at partial + q * blocks * k keys, blocks =
 // scan_grid_blocks(s, t, masked), rank-major as above) are bit for bit what launch_scan_float writes
-// for it alone. Query q starts at d_queries + q * query_stride floats and is searched under
-// d_cand_of[q] if `d_cand_of` (a device array of n_q device pointers, entries nullable) is given,
-// else under `cand` (nullable); masked = either is non-null. `partial` needs n_q times
-// scan_partial_bytes. The caller merges, e.g. all queries in one launch_merge_batch.
+// for it alone. Query q starts at d_queries + q * query_stride floats and is searched under `cand`
+// (nullable) over `s` -- or, if `d_jobs` (a device array of n_q entries) is given, as d_jobs[q] says;
+// `s` must then be the LARGEST of the jobs' slabs (it sizes the grid). masked = cand or d_jobs given.
+// `partial` needs n_q times scan_partial_bytes. The caller merges, e.g. all queries in one
+// launch_merge_batch.
 hipError_t launch_scan_float_queries(const SlabView& s, const float* d_queries, uint32_t query_stride,
-                                     uint32_t n_q, const uint64_t* cand, const uint64_t* const* d_cand_of,
+                                     uint32_t n_q, const uint64_t* cand, const ScanJob* d_jobs,
                                      uint32_t k, uint64_t* partial, const ScanTuning& t, hipStream_t stream);
 // The same over a VS_BIN1 slab; query_stride in 16-byte vectors.
 hipError_t launch_scan_hamming_queries(const SlabView& s, const void* d_queries, uint32_t query_stride,
-                                       uint32_t n_q, const uint64_t* cand, const uint64_t* const* d_cand_of,
+                                       uint32_t n_q, const uint64_t* cand, const ScanJob* d_jobs,
                                        uint32_t k, uint64_t* partial, const ScanTuning& t, hipStream_t stream);
 
 // Up to scan_multi_queries(s) queries (eight for f32 rows of up to 768 dimensions, else four) in

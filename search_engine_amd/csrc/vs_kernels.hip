@@ -50,7 +50,7 @@ struct ScanArgs {
     uint32_t n_q = 1;
     uint32_t query_stride = 0;            // floats (Hamming: 16-byte vectors) between consecutive queries
     uint64_t partial_stride = 0;          // keys between consecutive queries' partial lists
-    const uint64_t* const* cand_of = nullptr;  // nullable: one candidate mask per query (entries nullable) instead of `cand`
+    const ScanJob* jobs = nullptr;        // nullable: query y is searched as jobs[y] says instead (n_q entries)
     uint32_t list_bufs = 1;               // 2: the waves' LDS lists alternate between two buffers from query to query
 };
 
@@ -295,7 +295,8 @@ __device__ __forceinline__ bool sample_is_dense(uint64_t first_batch, uint64_t n
 
 // Workgroup epilogue: wave 0 absorbs the other waves' lists and writes the
 // workgroup's k best, rank-major, to partial[rank * gridDim.x + blockIdx.x].
-__device__ __forceinline__ void finish_block(WaveTopK& top, unsigned char* smem, int k, uint32_t wib,
+template <typename TopK>
+__device__ __forceinline__ void finish_block(TopK& top, unsigned char* smem, int k, uint32_t wib,
                                              int lane, uint64_t* partial) {
     top.spill();
     __syncthreads();
@@ -334,35 +335,53 @@ __device__ __forceinline__ void scan_float_rows(const ScanArgs& a, unsigned char
     bool idle = false, have_first = false;
     uint64_t first_batch = 0;
     bool dense = a.cand == nullptr;
-    if (a.pair && !a.cand_of) {
+    if (a.pair && !a.jobs) {
         idle = pair_up_waves(a.present, a.cand, a.n_slots, lane, wib, 1, 6, &w, &W, &first_batch, &dense);
         have_first = true;
-    } else if (gridDim.y > 1 && a.cand && !a.cand_of) {
+    } else if (gridDim.y > 1 && a.cand && !a.jobs) {
         first_batch = first_mask_words(a.present, a.cand, a.n_slots, w, W, lane);
         have_first = true;
         dense = sample_is_dense(first_batch, a.n_slots, w, W, 1, 6);
     }
     uint32_t y0, y_step;
-    if (!split_queries(dense && !a.cand_of, &y0, &y_step)) return;
+    if (!split_queries(dense && !a.jobs, &y0, &y_step)) return;
+
+    // the common arguments, or (per query) what its job says
+    const u32x4* rows = a.rows;
+    const float* norms = a.norms;
+    const uint64_t* present = a.present;
+    const uint64_t* cand = a.cand;
+    uint64_t n_slots = a.n_slots;
+    uint32_t docid_base = a.docid_base;
 
     uint32_t turn = 0;
     for (uint32_t y = y0; y < a.n_q; y += y_step, ++turn) {
-        const uint64_t* cand = a.cand_of ? a.cand_of[y] : a.cand;
-        if (a.cand_of) {
+        const float* query = a.query + (size_t)y * a.query_stride;
+        if (a.jobs) {
+            const ScanJob& job = a.jobs[y];
+            rows = reinterpret_cast<const u32x4*>(job.rows);
+            norms = job.norms;
+            present = job.present;
+            cand = job.cand;
+            n_slots = job.n_slots;
+            docid_base = job.docid_base;
+            if (job.query) query = static_cast<const float*>(job.query);
             W = W0;
             w = w0;
             idle = have_first = false;
             if (a.pair && cand) {
-                idle = pair_up_waves(a.present, cand, a.n_slots, lane, wib, 1, 6, &w, &W, &first_batch);
+                idle = pair_up_waves(present, cand, n_slots, lane, wib, 1, 6, &w, &W, &first_batch);
                 have_first = true;
             }
         }
         unsigned char* lists = smem + (a.list_bufs > 1 ? (turn & 1) * list_bytes : 0);
         WaveTopK top;
         top.init(reinterpret_cast<uint64_t*>(lists) + (size_t)wib * k, k, lane);
+        if (WaveTopK::needs_park_buffer(a.k))  // (the launcher adds the buffers behind the queues)
+            top.park_in(reinterpret_cast<uint64_t*>(smem + a.list_bufs * list_bytes + (size_t)WAVES * QCAP * 4) +
+                        (size_t)wib * 128);
 
         // this lane's slice of the query, and ‖q‖ summed in the row order
-        const float* query = a.query + (size_t)y * a.query_stride;
         float q[NCH][EPV];
         float qq = 0.0f;
 #pragma unroll
@@ -379,6 +398,7 @@ __device__ __forceinline__ void scan_float_rows(const ScanArgs& a, unsigned char
 
         // Scores rows queue[head .. head+U); the first `nvalid` of them count.
         auto score_rows = [&](uint32_t head, uint32_t nvalid) {
+            top.make_room(U);
             uint32_t slot[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -389,7 +409,7 @@ __device__ __forceinline__ void scan_float_rows(const ScanArgs& a, unsigned char
             float pn[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const u32x4* rp = a.rows + (uint64_t)slot[u] * a.row_vecs;
+                const u32x4* rp = rows + (uint64_t)slot[u] * a.row_vecs;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     const uint32_t idx = (uint32_t)(c * 64 + lane);
@@ -399,7 +419,7 @@ __device__ __forceinline__ void scan_float_rows(const ScanArgs& a, unsigned char
                         x[u][c] = u32x4{0u, 0u, 0u, 0u};
                     }
                 }
-                pn[u] = METRIC == VS_ANGULAR ? a.norms[slot[u]] : 0.0f;
+                pn[u] = METRIC == VS_ANGULAR ? norms[slot[u]] : 0.0f;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -412,13 +432,13 @@ __device__ __forceinline__ void scan_float_rows(const ScanArgs& a, unsigned char
                 const float d = METRIC == VS_ANGULAR     ? angular_distance(pq, pn[u], qn)
                                 : METRIC == VS_EUCLIDEAN ? pq
                                                          : -pq;
-                const uint64_t key = make_key(uniform_u32(f32_orderable(d)), a.docid_base + slot[u]);
+                const uint64_t key = make_key(uniform_u32(f32_orderable(d)), docid_base + slot[u]);
                 if ((uint32_t)u < nvalid && key < top.tau) top.insert(key);
             }
         };
 
         if (!idle)
-            scan_masked_slots<U>(a.present, cand, a.n_slots, w, W, lane, queue, score_rows, NoDenseFn(), EveryWord(),
+            scan_masked_slots<U>(present, cand, n_slots, w, W, lane, queue, score_rows, NoDenseFn(), EveryWord(),
                                  have_first, first_batch);
         finish_block(top, lists, k, wib, lane, a.partial + (uint64_t)y * a.partial_stride);
         // one list buffer only: wave 0 must be through with it before the next query's lists go there
@@ -508,7 +528,7 @@ __global__ __launch_bounds__(WAVES * 64) void scan_multi_kernel(MultiArgs m) {
 
     uint32_t* queue =
         reinterpret_cast<uint32_t*>(smem + (size_t)Q * WAVES * k * 8) + (size_t)wib * QCAP;
-    WaveTopK top[Q];
+    WaveTopKRegs top[Q];  // (k <= 128 here)
 #pragma unroll
     for (int q = 0; q < Q; ++q)
         top[q].init(reinterpret_cast<uint64_t*>(smem) + ((size_t)q * WAVES + wib) * k, k, lane);
@@ -1050,7 +1070,7 @@ struct HammingArgs {
     uint32_t n_q = 1;
     uint32_t query_stride = 0;    // 16-byte vectors between consecutive queries
     uint64_t partial_stride = 0;  // keys between consecutive queries' partial lists
-    const uint64_t* const* cand_of = nullptr;
+    const ScanJob* jobs = nullptr;
     uint32_t list_bufs = 1;
 };
 
@@ -1141,26 +1161,40 @@ __global__ __launch_bounds__(WAVES * 64) void scan_hamming_kernel(HammingArgs a)
     bool idle = false, have_first = false;
     uint64_t first_batch = 0;
     bool dense = a.cand == nullptr;
-    if (a.pair && !a.cand_of) {
+    if (a.pair && !a.jobs) {
         idle = pair_up_waves(a.present, a.cand, a.n_slots, lane, wib, 7, 8, &w, &W, &first_batch, &dense);
         have_first = true;
-    } else if (gridDim.y > 1 && a.cand && !a.cand_of) {
+    } else if (gridDim.y > 1 && a.cand && !a.jobs) {
         first_batch = first_mask_words(a.present, a.cand, a.n_slots, w, W, lane);
         have_first = true;
         dense = sample_is_dense(first_batch, a.n_slots, w, W, 7, 8);
     }
     uint32_t y0, y_step;
-    if (!split_queries(dense && !a.cand_of, &y0, &y_step)) return;
+    if (!split_queries(dense && !a.jobs, &y0, &y_step)) return;
+
+    // the common arguments, or (per query) what its job says
+    const u32x4* rows = a.rows;
+    const uint64_t* present = a.present;
+    const uint64_t* cand = a.cand;
+    uint64_t n_slots = a.n_slots;
+    uint32_t docid_base = a.docid_base;
 
     uint32_t turn = 0;
     for (uint32_t y = y0; y < a.n_q; y += y_step, ++turn) {
-        const uint64_t* cand = a.cand_of ? a.cand_of[y] : a.cand;
-        if (a.cand_of) {
+        const u32x4* query = a.query + (size_t)y * a.query_stride;
+        if (a.jobs) {
+            const ScanJob& job = a.jobs[y];
+            rows = reinterpret_cast<const u32x4*>(job.rows);
+            present = job.present;
+            cand = job.cand;
+            n_slots = job.n_slots;
+            docid_base = job.docid_base;
+            if (job.query) query = static_cast<const u32x4*>(job.query);
             W = W0;
             w = w0;
             idle = have_first = false;
             if (a.pair && cand) {
-                idle = pair_up_waves(a.present, cand, a.n_slots, lane, wib, 7, 8, &w, &W, &first_batch);
+                idle = pair_up_waves(present, cand, n_slots, lane, wib, 7, 8, &w, &W, &first_batch);
                 have_first = true;
             }
         }
@@ -1170,7 +1204,6 @@ __global__ __launch_bounds__(WAVES * 64) void scan_hamming_kernel(HammingArgs a)
         if (a.park) top.park_in(park_buffer);
 
         // this lane's share of the query: vectors sub, sub + 4, ...
-        const u32x4* query = a.query + (size_t)y * a.query_stride;
         u32x4 q[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -1187,7 +1220,7 @@ __global__ __launch_bounds__(WAVES * 64) void scan_hamming_kernel(HammingArgs a)
                 const uint32_t r = (uint32_t)(u * 16 + quad);
                 valid[u] = r < nvalid;
                 slot[u] = queue[head + (valid[u] ? r : 0u)];
-                const u32x4* rp = a.rows + (uint64_t)slot[u] * a.row_vecs;
+                const u32x4* rp = rows + (uint64_t)slot[u] * a.row_vecs;
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
                     const uint32_t p = (uint32_t)(i * 4 + sub);
@@ -1208,7 +1241,7 @@ __global__ __launch_bounds__(WAVES * 64) void scan_hamming_kernel(HammingArgs a)
                 }
                 cnt += dpp_u32<0xB1, 0xF>(cnt);  // quad_perm [1,0,3,2]
                 cnt += dpp_u32<0x4E, 0xF>(cnt);  // quad_perm [2,3,0,1]
-                const uint64_t key = make_key(cnt, a.docid_base + slot[u]);
+                const uint64_t key = make_key(cnt, docid_base + slot[u]);
                 const bool live = valid[u] && sub == 0;
                 if (top.parks()) {
                     top.park(live && key < top.tau, key);
@@ -1227,16 +1260,16 @@ __global__ __launch_bounds__(WAVES * 64) void scan_hamming_kernel(HammingArgs a)
         bool scanned = false;
         if constexpr (NI == 3) {
             if (a.row_vecs == 12) {  // 1536-bit rows: whole words of candidates go through the pair path
-                HammingPairs<NT> pairs{a.rows, a.docid_base, lane, &top};
+                HammingPairs<NT> pairs{rows, docid_base, lane, &top};
                 pairs.load_query(query);
                 if (!idle)
-                    scan_masked_slots<16 * U>(a.present, cand, a.n_slots, w, W, lane, queue, score_rows, pairs,
+                    scan_masked_slots<16 * U>(present, cand, n_slots, w, W, lane, queue, score_rows, pairs,
                                               EveryWord(), have_first, first_batch);
                 scanned = true;
             }
         }
         if (!scanned && !idle)
-            scan_masked_slots<16 * U>(a.present, cand, a.n_slots, w, W, lane, queue, score_rows, NoDenseFn(),
+            scan_masked_slots<16 * U>(present, cand, n_slots, w, W, lane, queue, score_rows, NoDenseFn(),
                                       EveryWord(), have_first, first_batch);
         top.merge_parked();
         finish_block(top, lists, k, wib, lane, a.partial + (uint64_t)y * a.partial_stride);
@@ -1272,7 +1305,7 @@ __global__ __launch_bounds__(WAVES * 64) void scan_hamming_multi_kernel(HammingM
     const int k = (int)a.k;
     uint32_t* queue =
         reinterpret_cast<uint32_t*>(smem + (size_t)HQ * WAVES * k * 8) + (size_t)wib * QCAP;
-    WaveTopK top[HQ];
+    WaveTopKRegs top[HQ];  // (k <= 128 here)
 #pragma unroll
     for (int q = 0; q < HQ; ++q)
         top[q].init(reinterpret_cast<uint64_t*>(smem) + ((size_t)q * WAVES + wib) * k, k, lane);
@@ -1388,6 +1421,7 @@ __global__ __launch_bounds__(256) void merge_kernel(const uint64_t* keys, uint32
     const int k = (int)k_;
     WaveTopK top;
     top.init(reinterpret_cast<uint64_t*>(smem) + (size_t)wv * k, k, lane);
+    if (WaveTopK::needs_park_buffer(k_)) top.park_in(reinterpret_cast<uint64_t*>(smem) + (size_t)4 * k + (size_t)wv * 128);
 
     for (uint32_t base = 0; base < n_lists; base += 1024) {
         auto load_rank = [&](uint32_t r, uint64_t (&dst)[4]) {
@@ -1419,6 +1453,12 @@ __global__ __launch_bounds__(256) void merge_kernel(const uint64_t* keys, uint32
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 if (b < b0) continue;
+                if (!top.in_regs) {  // lists in LDS take their keys a batch at a time
+                    const bool mine = key[b] < top.tau;
+                    if (__ballot(mine)) any = true;
+                    top.park(mine, key[b]);
+                    continue;
+                }
                 uint64_t m = __ballot(key[b] < top.tau);
                 while (m) {
                     const int src = __builtin_ctzll(m);
@@ -1699,10 +1739,10 @@ static uint32_t scan_query_lanes(uint32_t n_q, const ScanTuning& t) {
 }
 
 hipError_t launch_scan_float_queries(const SlabView& s, const float* d_queries, uint32_t query_stride,
-                                     uint32_t n_q, const uint64_t* cand, const uint64_t* const* d_cand_of,
+                                     uint32_t n_q, const uint64_t* cand, const ScanJob* d_jobs,
                                      uint32_t k, uint64_t* partial, const ScanTuning& t, hipStream_t stream) {
     if (k == 0 || k > VS_MAX_K || (s.n_slots & 63) || s.n_slots == 0 || n_q == 0) return hipErrorInvalidValue;
-    const bool masked = cand != nullptr || d_cand_of != nullptr;
+    const bool masked = cand != nullptr || d_jobs != nullptr;
     ScanArgs a;
     a.rows = reinterpret_cast<const u32x4*>(s.rows);
     a.norms = s.norms;
@@ -1728,9 +1768,10 @@ hipError_t launch_scan_float_queries(const SlabView& s, const float* d_queries, 
     a.n_q = n_q;
     a.query_stride = query_stride;
     a.partial_stride = (uint64_t)blocks * k;
-    a.cand_of = d_cand_of;
+    a.jobs = d_jobs;
     a.list_bufs = (n_q > 1 && k <= (uint32_t)WaveTopK::REG_K) ? 2u : 1u;
-    const size_t lds = (size_t)a.list_bufs * WAVES * k * 8 + (size_t)WAVES * QCAP * 4;
+    const size_t lds = (size_t)a.list_bufs * WAVES * k * 8 + (size_t)WAVES * QCAP * 4 +
+                       (WaveTopK::needs_park_buffer(k) ? (size_t)WAVES * 128 * 8 : 0);
     if (s.dtype == VS_F32) return launch_scan_e<VS_F32>(a, blocks, lanes, lds, t, stream);
     if (s.dtype == VS_BF16) return launch_scan_e<VS_BF16>(a, blocks, lanes, lds, t, stream);
     return hipErrorInvalidValue;
@@ -1760,11 +1801,11 @@ static hipError_t launch_hamming_t(const HammingArgs& a, uint32_t blocks, uint32
 }
 
 hipError_t launch_scan_hamming_queries(const SlabView& s, const void* d_queries, uint32_t query_stride,
-                                       uint32_t n_q, const uint64_t* cand, const uint64_t* const* d_cand_of,
+                                       uint32_t n_q, const uint64_t* cand, const ScanJob* d_jobs,
                                        uint32_t k, uint64_t* partial, const ScanTuning& t, hipStream_t stream) {
     if (k == 0 || k > VS_MAX_K || (s.n_slots & 63) || s.n_slots == 0 || s.dtype != VS_BIN1 || n_q == 0)
         return hipErrorInvalidValue;
-    const bool masked = cand != nullptr || d_cand_of != nullptr;
+    const bool masked = cand != nullptr || d_jobs != nullptr;
     HammingArgs a;
     a.rows = reinterpret_cast<const u32x4*>(s.rows);
     a.present = s.present;
@@ -1776,7 +1817,8 @@ hipError_t launch_scan_hamming_queries(const SlabView& s, const void* d_queries,
     a.docid_base = s.docid_base;
     a.k = k;
     // top-100 under a filter: an insert at a time was 30 to 40 us of every launch (50 M x 1536 bit)
-    a.park = (k > 32 && k <= (uint32_t)WaveTopK::REG_K) ? 1u : 0u;
+    // (lists beyond the registers, k > 128, cannot take a key at a time at all)
+    a.park = k > 32 ? 1u : 0u;
     const uint32_t blocks = scan_grid_blocks(s, t, masked);
     // the default grid under a filter is two workgroups per CU: let them pair up where the rows
     // have the whole-word path (1536 bits)
@@ -1785,7 +1827,7 @@ hipError_t launch_scan_hamming_queries(const SlabView& s, const void* d_queries,
     a.n_q = n_q;
     a.query_stride = query_stride;
     a.partial_stride = (uint64_t)blocks * k;
-    a.cand_of = d_cand_of;
+    a.jobs = d_jobs;
     a.list_bufs = (n_q > 1 && k <= (uint32_t)WaveTopK::REG_K) ? 2u : 1u;
     const size_t lds = (size_t)a.list_bufs * WAVES * k * 8 + (size_t)WAVES * QCAP * 4 + (a.park ? (size_t)WAVES * 128 * 8 : 0);
     const uint32_t ni = (s.row_vecs + 3) / 4;
@@ -2041,7 +2083,8 @@ hipError_t launch_merge_batch(const uint64_t* keys, uint32_t n_lists, uint64_t l
         rank_stride = 0;
         n_ranks = 1;
     }
-    hipLaunchKernelGGL(merge_kernel, dim3(n_queries), dim3(256), (size_t)4 * k * 8, stream, keys,
+    const size_t lds = (size_t)4 * k * 8 + (WaveTopK::needs_park_buffer(k) ? (size_t)4 * 128 * 8 : 0);
+    hipLaunchKernelGGL(merge_kernel, dim3(n_queries), dim3(256), lds, stream, keys,
                        n_lists, list_stride, rank_stride, n_ranks, query_stride, k, metric, out_keys,
                        out_ids, out_dist, out_n, gate);
     return hipGetLastError();

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 
 #include "vs_internal.h"
@@ -165,13 +166,13 @@ int32_t launch_scan(const vs::SlabView& v, const vs::ScanTuning& t, const void* 
 
 int32_t launch_scan_queries(const vs::SlabView& v, const vs::ScanTuning& t, const void* d_queries,
                             size_t query_bytes, uint32_t n_q, const uint64_t* d_cand,
-                            const uint64_t* const* d_cand_of, uint32_t k, uint64_t* d_partial, hipStream_t stream) {
+                            const vs::ScanJob* d_jobs, uint32_t k, uint64_t* d_partial, hipStream_t stream) {
     if (v.metric == VS_HAMMING)
-        HIP_TRY(vs::launch_scan_hamming_queries(v, d_queries, (uint32_t)(query_bytes / 16), n_q, d_cand, d_cand_of, k,
+        HIP_TRY(vs::launch_scan_hamming_queries(v, d_queries, (uint32_t)(query_bytes / 16), n_q, d_cand, d_jobs, k,
                                                 d_partial, t, stream));
     else
         HIP_TRY(vs::launch_scan_float_queries(v, static_cast<const float*>(d_queries), (uint32_t)(query_bytes / 4),
-                                              n_q, d_cand, d_cand_of, k, d_partial, t, stream));
+                                              n_q, d_cand, d_jobs, k, d_partial, t, stream));
     return VS_OK;
 }
 
@@ -382,6 +383,17 @@ int32_t run_batch_and_fetch(vs_store* s, const vs::SlabView& v, Workspace* ws, c
     return VS_OK;
 }
 
+// Makes the workspace's pinned host block at least `bytes` long (contents are not kept).
+int32_t grow_pinned(Workspace* ws, size_t bytes) {
+    if (ws->pinned_bytes >= bytes) return VS_OK;
+    unsigned char* fresh = nullptr;
+    HIP_TRY(hipHostMalloc(&fresh, bytes, hipHostMallocDefault));
+    if (ws->h_pinned) (void)hipHostFree(ws->h_pinned);
+    ws->h_pinned = fresh;
+    ws->pinned_bytes = bytes;
+    return VS_OK;
+}
+
 // Packs one host query the way the device takes it: f32 as it is, binary stores quantised like the
 // rows (bit j = (q[j] > 0), zero padded to whole vectors).
 void pack_query(const vs_store* s, const float* q, unsigned char* dst, size_t q_bytes) {
@@ -397,8 +409,8 @@ void pack_query(const vs_store* s, const float* q, unsigned char* dst, size_t q_
 
 // `n_q` independent single-query searches, host queries and host results, with ONE scan launch, one
 // merge launch and one wait per chunk of queries: query i runs under d_cand_of[i] (device words
-// aligned with the store, nullable) if `d_cand_of` is given, else under d_cand (nullable). No row read
-// is shared, so result i is bit for bit vs_search's.
+// aligned with the store, nullable; the array itself is host memory) if `d_cand_of` is given, else
+// under d_cand (nullable). No row read is shared, so result i is bit for bit vs_search's.
 int32_t run_queries_and_fetch(vs_store* s, const vs::SlabView& v, Workspace* ws, const float* h_queries,
                               uint32_t n_q, uint32_t k, const uint64_t* d_cand,
                               const uint64_t* const* d_cand_of, uint32_t* out_ids, float* out_dist,
@@ -414,8 +426,9 @@ int32_t run_queries_and_fetch(vs_store* s, const vs::SlabView& v, Workspace* ws,
     if (int32_t rc = grow(&ws->d_partial, &ws->partial_bytes, chunk_q * per_query)) return rc;
     const size_t q_bytes = s->dtype == VS_BIN1 ? (size_t)s->row_vecs * 16 : (size_t)s->dim * 4;
     const size_t q_stride = (q_bytes + 255) / 256 * 256;
-    // one device block and one host block: queries | mask pointers | ids, distances, counts
-    const size_t off_tab = chunk_q * q_stride, off_res = off_tab + (chunk_q * 8 + 255) / 256 * 256;
+    // one device block and one host block: queries | the queries' jobs | ids, distances, counts
+    const size_t off_tab = chunk_q * q_stride,
+                 off_res = off_tab + (chunk_q * sizeof(vs::ScanJob) + 255) / 256 * 256;
     const size_t res_bytes = chunk_q * k * 8 + chunk_q * 4;
     if (int32_t rc = grow(&ws->d_batch, &ws->batch_bytes, off_res + res_bytes)) return rc;
     std::vector<unsigned char> up(off_res), down(res_bytes);
@@ -423,17 +436,21 @@ int32_t run_queries_and_fetch(vs_store* s, const vs::SlabView& v, Workspace* ws,
         const uint32_t m = n_q - at < chunk_q ? n_q - at : (uint32_t)chunk_q;
         for (uint32_t i = 0; i < m; ++i)
             pack_query(s, h_queries + (size_t)(at + i) * s->dim, up.data() + i * q_stride, q_bytes);
-        if (d_cand_of) memcpy(up.data() + off_tab, d_cand_of + at, (size_t)m * 8);
+        if (d_cand_of) {  // every query over this store, each under its own mask
+            vs::ScanJob* jobs = reinterpret_cast<vs::ScanJob*>(up.data() + off_tab);
+            for (uint32_t i = 0; i < m; ++i)
+                jobs[i] = vs::ScanJob{v.rows, v.norms, v.present, d_cand_of[at + i], nullptr, v.n_slots, v.docid_base, 0};
+        }
         unsigned char* d_res = ws->d_batch + off_res;
         uint32_t* d_ids = reinterpret_cast<uint32_t*>(d_res);
         float* d_dist = reinterpret_cast<float*>(d_res + chunk_q * k * 4);
         uint32_t* d_n = reinterpret_cast<uint32_t*>(d_res + chunk_q * k * 8);
-        HIP_TRY(hipMemcpyAsync(ws->d_batch, up.data(), off_tab + (d_cand_of ? (size_t)m * 8 : 0), hipMemcpyHostToDevice,
-                               ws->stream));
+        HIP_TRY(hipMemcpyAsync(ws->d_batch, up.data(), off_tab + (d_cand_of ? (size_t)m * sizeof(vs::ScanJob) : 0),
+                               hipMemcpyHostToDevice, ws->stream));
         if (int32_t rc = launch_scan_queries(
                 v, t, ws->d_batch, q_stride, m, d_cand,
-                d_cand_of ? reinterpret_cast<const uint64_t* const*>(ws->d_batch + off_tab) : nullptr, k,
-                ws->d_partial, ws->stream))
+                d_cand_of ? reinterpret_cast<const vs::ScanJob*>(ws->d_batch + off_tab) : nullptr, k, ws->d_partial,
+                ws->stream))
             return rc;
         HIP_TRY(vs::launch_merge_batch(ws->d_partial, blocks, 1, blocks, m, (uint64_t)blocks * k, k, v.metric, nullptr,
                                        d_ids, d_dist, d_n, ws->stream));
@@ -515,17 +532,22 @@ int32_t run_many_and_fetch(vs_store* s, const vs::SlabView& v, Workspace* ws, co
     return VS_OK;
 }
 
-// Copies the caller's docid-indexed mask into `d_words` (n_slots / 64 words), aligned to the store.
-int32_t copy_dense_mask(vs_store* s, hipStream_t stream, uint64_t* d_words, const uint64_t* mask_words,
-                        uint64_t n_mask_words) {
-    const uint64_t n_words = s->n_slots / 64;
-    const uint64_t w0 = s->docid_base / 64;
+// Copies the caller's docid-indexed mask into `d_words`: n_words words covering the docids from
+// docid_base (a multiple of 64) on.
+int32_t copy_dense_window(hipStream_t stream, uint64_t* d_words, uint32_t docid_base, uint64_t n_words,
+                          const uint64_t* mask_words, uint64_t n_mask_words) {
+    const uint64_t w0 = docid_base / 64;
     const uint64_t avail = n_mask_words > w0 ? n_mask_words - w0 : 0;
     const uint64_t ncopy = avail < n_words ? avail : n_words;
     if (ncopy)
         HIP_TRY(hipMemcpyAsync(d_words, mask_words + w0, (size_t)ncopy * 8, hipMemcpyHostToDevice, stream));
     if (ncopy < n_words) HIP_TRY(hipMemsetAsync(d_words + ncopy, 0, (size_t)(n_words - ncopy) * 8, stream));
     return VS_OK;
+}
+// ... aligned to the store (n_slots / 64 words)
+int32_t copy_dense_mask(vs_store* s, hipStream_t stream, uint64_t* d_words, const uint64_t* mask_words,
+                        uint64_t n_mask_words) {
+    return copy_dense_window(stream, d_words, s->docid_base, s->n_slots / 64, mask_words, n_mask_words);
 }
 // ... into ws->d_mask
 int32_t stage_dense_mask(vs_store* s, Workspace* ws, const uint64_t* mask_words,
@@ -534,10 +556,11 @@ int32_t stage_dense_mask(vs_store* s, Workspace* ws, const uint64_t* mask_words,
     return copy_dense_mask(s, ws->stream, ws->d_mask, mask_words, n_mask_words);
 }
 
-// Expands a parsed serialised RoaringBitmap into `d_words` (n_slots / 64 words aligned with the store).
-int32_t expand_roaring(vs_store* s, Workspace* ws, const uint8_t* roaring_bytes, size_t len,
-                       const std::vector<vs::RoaringContainerDesc>& desc, uint64_t* d_words) {
-    const uint64_t n_words = s->n_slots / 64;
+// Expands a parsed serialised RoaringBitmap into `d_words`: n_words words covering the docids from
+// docid_base on.
+int32_t expand_roaring_window(Workspace* ws, const uint8_t* roaring_bytes, size_t len,
+                              const std::vector<vs::RoaringContainerDesc>& desc, uint32_t docid_base,
+                              uint64_t n_words, uint64_t* d_words) {
     HIP_TRY(hipMemsetAsync(d_words, 0, (size_t)n_words * 8, ws->stream));
     if (desc.empty()) return VS_OK;
     const size_t blob = (len + 15) / 16 * 16;
@@ -547,8 +570,13 @@ int32_t expand_roaring(vs_store* s, Workspace* ws, const uint8_t* roaring_bytes,
     HIP_TRY(hipMemcpyAsync(ws->d_blob + blob, desc.data(), desc_b, hipMemcpyHostToDevice, ws->stream));
     HIP_TRY(vs::launch_roaring_expand(ws->d_blob,
                                       reinterpret_cast<const vs::RoaringContainerDesc*>(ws->d_blob + blob),
-                                      (uint32_t)desc.size(), s->docid_base, d_words, n_words, ws->stream));
+                                      (uint32_t)desc.size(), docid_base, d_words, n_words, ws->stream));
     return VS_OK;
+}
+// ... aligned with the store (n_slots / 64 words)
+int32_t expand_roaring(vs_store* s, Workspace* ws, const uint8_t* roaring_bytes, size_t len,
+                       const std::vector<vs::RoaringContainerDesc>& desc, uint64_t* d_words) {
+    return expand_roaring_window(ws, roaring_bytes, len, desc, s->docid_base, s->n_slots / 64, d_words);
 }
 
 // A host-buffer search from begin to end: workspace, snapshot, body, release. `body` gets the
@@ -1181,7 +1209,7 @@ int32_t mask_new(vs_store* s, vs_mask** out, std::unique_ptr<vs_mask>* m) {
     if (!out) return fail(VS_E_INVALID_ARG, "null out pointer");
     *out = nullptr;
     if (int32_t rc = check_store(s)) return rc;
-    m->reset(new vs_mask{s, nullptr, s->n_slots, s->serial});
+    m->reset(new vs_mask{s, nullptr, s->n_slots, s->serial, s->docid_base});
     if (hipMalloc(&(*m)->d_words, (size_t)(s->n_slots / 64) * 8) != hipSuccess)
         return fail(VS_E_OOM, "cannot allocate a %llu-byte mask", (unsigned long long)(s->n_slots / 8));
     return VS_OK;
@@ -1406,6 +1434,155 @@ extern "C" int32_t vs_search_batch_masks(vs_store* s, const float* queries, uint
         }
         return VS_OK;
     });
+}
+
+// ---- one query against every vector store of an embedder --------------------------------------
+
+extern "C" int32_t vs_search_stores(vs_ctx* ctx, uint16_t store_index_base, const float* query, uint32_t dim,
+                                    uint32_t k, const uint64_t* mask_words, uint64_t n_mask_words,
+                                    const uint8_t* roaring_bytes, size_t roaring_len, const vs_mask* mask,
+                                    uint32_t* out_ids, float* out_dist, uint8_t* out_store, uint32_t out_cap,
+                                    uint32_t* out_n, uint32_t* out_n_stores) {
+    if (!ctx || !query || !out_n || !out_n_stores) return fail(VS_E_INVALID_ARG, "null argument");
+    *out_n = 0;
+    *out_n_stores = 0;
+    if (store_index_base & 0xFF)
+        return fail(VS_E_INVALID_ARG, "store_index_base %u: the low byte numbers a document's vectors and must be 0",
+                    store_index_base);
+    if ((mask_words != nullptr) + (roaring_bytes != nullptr) + (mask != nullptr) > 1)
+        return fail(VS_E_INVALID_ARG, "one filter at most: dense words, a serialised RoaringBitmap or a vs_mask");
+    if (k > VS_MAX_K) return fail(VS_E_INVALID_ARG, "k = %u exceeds VS_MAX_K = %u", k, VS_MAX_K);
+    HIP_TRY(hipSetDevice(ctx->device));
+    // the stores (base | 0), (base | 1), ... up to the first that is missing or was never sealed
+    std::vector<vs_store*> stores;
+    {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        for (uint32_t j = 0; j <= 0xFF; ++j) {
+            auto it = ctx->stores.find((uint16_t)(store_index_base | j));
+            if (it == ctx->stores.end() || !it->second->sealed.load()) break;
+            stores.push_back(it->second);
+        }
+    }
+    const uint32_t n_stores = (uint32_t)stores.size();
+    *out_n_stores = n_stores;
+    if (n_stores == 0 || k == 0) return VS_OK;  // no reader opens: nothing to search
+    if ((uint64_t)n_stores * k > out_cap)
+        return fail(VS_E_CAPACITY, "%u stores x k = %u need %llu output entries, %u given", n_stores, k,
+                    (unsigned long long)n_stores * k, out_cap);
+    if (!out_ids || !out_dist || !out_store) return fail(VS_E_INVALID_ARG, "null output buffer");
+    std::vector<vs::RoaringContainerDesc> desc;
+    if (roaring_bytes && !vs::roaring_parse(roaring_bytes, roaring_len, &desc))
+        return fail(VS_E_FORMAT, "malformed serialised RoaringBitmap (%zu bytes)", roaring_len);
+    for (vs_store* s : stores) {
+        if (s->dim != dim) {
+            set_dim_mismatch(s->dim, dim);
+            return fail(VS_E_DIM_MISMATCH, "invalid vector dimensions: expected %u, received %u", s->dim, dim);
+        }
+        if (s->dtype != stores[0]->dtype || s->metric != stores[0]->metric)
+            return fail(VS_E_INVALID_ARG, "stores %u and %u differ in element type or metric", stores[0]->index, s->index);
+    }
+    std::unique_ptr<Workspace> ws;
+    if (int32_t rc = ws_acquire(ctx, &ws)) return rc;
+    std::vector<Snapshot> snaps(n_stores);
+    for (uint32_t j = 0; j < n_stores; ++j) snapshot_begin(stores[j], &snaps[j]);
+    auto body = [&]() -> int32_t {
+        // the filter goes to the device ONCE, as words over the docid window all stores lie in; every
+        // store reads it from its own offset
+        uint64_t lo = ~0ull, hi = 0;
+        for (uint32_t j = 0; j < n_stores; ++j) {
+            const vs::SlabView& v = snaps[j].v;
+            lo = v.docid_base < lo ? v.docid_base : lo;
+            hi = v.docid_base + v.n_slots > hi ? v.docid_base + v.n_slots : hi;
+        }
+        const uint64_t window_words = (hi - lo) / 64;
+        const uint64_t* d_window = nullptr;
+        if (mask) {
+            // a mask made for one of these stores serves all that start at its docid and are not larger
+            bool owner = false;
+            for (vs_store* s : stores) owner = owner || vs_mask_fits(s, mask);
+            if (!owner) return fail(VS_E_INVALID_ARG, "the mask was created for none of these stores as they are now");
+            for (uint32_t j = 0; j < n_stores; ++j)
+                if (snaps[j].v.docid_base != mask->docid_base || snaps[j].v.n_slots > mask->n_slots)
+                    return fail(VS_E_INVALID_ARG, "store %u does not lie inside the mask's docid range", stores[j]->index);
+        } else if (mask_words || roaring_bytes) {
+            if (int32_t rc = grow(&ws->d_mask, &ws->mask_words, (size_t)window_words * 8)) return rc;
+            if (mask_words) {
+                if (int32_t rc = copy_dense_window(ws->stream, ws->d_mask, (uint32_t)lo, window_words, mask_words, n_mask_words))
+                    return rc;
+            } else if (int32_t rc = expand_roaring_window(ws.get(), roaring_bytes, roaring_len, desc, (uint32_t)lo,
+                                                          window_words, ws->d_mask)) {
+                return rc;
+            }
+            d_window = ws->d_mask;
+        }
+        const vs::ScanTuning t = tuning_of(ctx);
+        // ONE scan launch takes all stores, a job each (its own slab, the common query, the filter from
+        // its own offset), and one merge launch writes every store's k results straight into pinned host
+        // memory (mapped into the device's address space): no copy back, one wait.
+        uint32_t big = 0;
+        for (uint32_t j = 1; j < n_stores; ++j)
+            if (snaps[j].v.n_slots > snaps[big].v.n_slots) big = j;
+        const vs::SlabView& vbig = snaps[big].v;
+        const uint32_t blocks = vs::scan_grid_blocks(vbig, t, true);
+        const size_t q_bytes = stores[0]->dtype == VS_BIN1 ? (size_t)stores[0]->row_vecs * 16 : (size_t)dim * 4;
+        const size_t off_jobs = (q_bytes + 255) / 256 * 256, jobs_bytes = n_stores * sizeof(vs::ScanJob);
+        const size_t res_bytes = (size_t)n_stores * k * 8 + (size_t)n_stores * 4;
+        if (int32_t rc = grow(&ws->d_batch, &ws->batch_bytes, off_jobs + jobs_bytes)) return rc;
+        if (int32_t rc = grow(&ws->d_partial, &ws->partial_bytes, (size_t)n_stores * blocks * k * 8)) return rc;
+        if (int32_t rc = grow_pinned(ws.get(), off_jobs + jobs_bytes + res_bytes)) return rc;
+        pack_query(stores[0], query, ws->h_pinned, q_bytes);
+        vs::ScanJob* jobs = reinterpret_cast<vs::ScanJob*>(ws->h_pinned + off_jobs);
+        for (uint32_t j = 0; j < n_stores; ++j) {
+            const vs::SlabView& v = snaps[j].v;
+            const uint64_t* d_cand = mask ? mask->d_words : d_window ? d_window + (v.docid_base - lo) / 64 : nullptr;
+            jobs[j] = vs::ScanJob{v.rows, v.norms, v.present, d_cand, nullptr, v.n_slots, v.docid_base, 0};
+        }
+        HIP_TRY(hipMemcpyAsync(ws->d_batch, ws->h_pinned, off_jobs + jobs_bytes, hipMemcpyHostToDevice, ws->stream));
+        if (int32_t rc = launch_scan_queries(vbig, t, ws->d_batch, 0, n_stores, nullptr,
+                                             reinterpret_cast<const vs::ScanJob*>(ws->d_batch + off_jobs), k,
+                                             ws->d_partial, ws->stream))
+            return rc;
+        unsigned char* hr = ws->h_pinned + off_jobs + jobs_bytes;
+        const uint32_t* h_ids = reinterpret_cast<const uint32_t*>(hr);
+        const float* h_dist = reinterpret_cast<const float*>(hr + (size_t)n_stores * k * 4);
+        const uint32_t* h_n = reinterpret_cast<const uint32_t*>(hr + (size_t)n_stores * k * 8);
+        HIP_TRY(vs::launch_merge_batch(ws->d_partial, blocks, 1, blocks, n_stores, (uint64_t)blocks * k, k, vbig.metric,
+                                       nullptr, const_cast<uint32_t*>(h_ids), const_cast<float*>(h_dist),
+                                       const_cast<uint32_t*>(h_n), ws->stream));
+        HIP_TRY(hipStreamSynchronize(ws->stream));
+        // every store's list is ascending by (distance, docid); the lists together go out ordered by
+        // (distance, docid, store), NaN last, which is the order VectorSort::fill_buffer sorts them into
+        struct Hit {
+            float d;
+            uint32_t id;
+            uint8_t store;
+        };
+        std::vector<Hit> hits;
+        hits.reserve((size_t)n_stores * k);
+        for (uint32_t j = 0; j < n_stores; ++j) {
+            const uint32_t n = h_n[j];
+            if (n > k) return fail(VS_E_DEVICE, "device returned %u results for k = %u", n, k);
+            for (uint32_t i = 0; i < n; ++i) hits.push_back(Hit{h_dist[(size_t)j * k + i], h_ids[(size_t)j * k + i], (uint8_t)j});
+        }
+        std::stable_sort(hits.begin(), hits.end(), [](const Hit& a, const Hit& b) {
+            const bool an = a.d != a.d, bn = b.d != b.d;
+            if (an != bn) return bn;
+            if (!an && a.d != b.d) return a.d < b.d;
+            return a.id < b.id;  // (equal distance and docid: the stable sort keeps the store order)
+        });
+        for (size_t i = 0; i < hits.size(); ++i) {
+            out_ids[i] = hits[i].id;
+            out_dist[i] = hits[i].d;
+            out_store[i] = hits[i].store;
+        }
+        *out_n = (uint32_t)hits.size();
+        return VS_OK;
+    };
+    const int32_t rc = body();
+    if (rc != VS_OK) (void)hipStreamSynchronize(ws->stream);  // nothing of a failed call stays in flight
+    for (uint32_t j = 0; j < n_stores; ++j) snapshot_end(stores[j], &snaps[j]);
+    ws_release(ctx, std::move(ws));
+    return rc;
 }
 
 // ---- search, device buffers ------------------------------------------------------------------

@@ -10,12 +10,19 @@ so these vectors do not come from the reference. They are
                     arithmetic evaluated in float64 below, no oracle code involved;
   shift.json        DistributionShift::shift (src/vector/mod.rs:405-432) evaluated
                     with numpy.float32 one operation at a time;
-  scan_small.json   a small seeded scan case with float64 distances from plain numpy.
+  scan_small.json   a small seeded scan case with float64 distances from plain numpy;
+  arroy_leaves.json the (key, value) pairs a cursor over the reference's `vector-arroy`
+                    database (src/index.rs:152-155, written by
+                    src/update/index_documents/typed_chunk.rs:601-606) would yield for that
+                    scenario, packed HERE with struct.pack from the layout arroy 0.2.0
+                    publishes (the crate is not in the reference tree: restated, not
+                    verified against it) -- bytes the library's own encoder never touched.
 Run from the repository root:  python tests/golden/make_golden.py
 """
 import json
 import math
 import os
+import struct
 
 import numpy as np
 
@@ -88,8 +95,38 @@ def scan_small():
             "top10_unfiltered": sorted(range(n), key=lambda i: (np.float32(d[i]), i))[:10]}
 
 
+def arroy_key(index, mode, item):
+    """index u16 big-endian | mode u8 (0 item, 1 tree, 2 metadata) | item u32 big-endian"""
+    return struct.pack(">HBI", index, mode, item)
+
+
+def arroy_leaf(vector):
+    """tag u8 = 0 | Angular header { norm f32 } | dim x f32, little endian"""
+    norm = math.sqrt(sum(float(np.float32(x)) ** 2 for x in vector))
+    return struct.pack("<Bf", 0, norm) + struct.pack(f"<{len(vector)}f", *vector)
+
+
+def arroy_leaves(category=7):
+    docs = {0: [[0, 1, 2], [3, 4, 5]], 1: [[6, 7, 8]], 2: [[9, 10, 11], [12, 13, 14], [15, 16, 17]]}
+    pairs = []
+    for doc, vecs in docs.items():
+        for j, v in enumerate(vecs):  # the j-th vector of a document lives in index (category << 8) | j
+            pairs.append((arroy_key((category << 8) | j, 0, doc), arroy_leaf(v)))
+    # what else a cursor yields: a split-plane tree node, a descendants node, metadata (payloads arbitrary:
+    # an exhaustive scan reads none of them), another embedder's item, a node mode of a later arroy
+    pairs.append((arroy_key(category << 8, 1, 9), struct.pack("<B3fII", 2, 0.5, -0.25, 0.125, 3, 4)))
+    pairs.append((arroy_key(category << 8, 1, 10), bytes([1]) + bytes.fromhex("3a300000010000000000020000000100")))
+    pairs.append((arroy_key(category << 8, 2, 0), struct.pack("<I", 3) + b"angular" + bytes(9)))
+    pairs.append((arroy_key(9 << 8, 0, 1), arroy_leaf([1, 1, 1])))
+    pairs.append((arroy_key(category << 8, 3, 2), b"\x00"))
+    pairs.sort()  # LMDB hands keys over in byte order
+    return {"category": category, "dim": 3, "pairs": [[k.hex(), v.hex()] for k, v in pairs],
+            "expect": {"n_items": 6, "n_other_nodes": 4, "n_unrouted": 1, "store_lens": [3, 2, 1]}}
+
+
 if __name__ == "__main__":
-    for name, obj in (("appendix_b", appendix_b()), ("shift", shift_cases()), ("scan_small", scan_small())):
+    for name, obj in (("appendix_b", appendix_b()), ("shift", shift_cases()), ("scan_small", scan_small()),
+                      ("arroy_leaves", arroy_leaves())):
         with open(os.path.join(HERE, name + ".json"), "w") as fh:
             json.dump(obj, fh, indent=1)
         print("wrote", name)

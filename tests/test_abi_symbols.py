@@ -15,9 +15,9 @@ def declared_entry_points():
 
 def test_header_declares_the_expected_surface():
     names = declared_entry_points()
-    assert len(names) >= 28
+    assert len(names) >= 29
     for must in ("vs_init", "vs_store_create", "vs_store_open", "vs_store_upload", "vs_store_seal",
-                 "vs_search", "vs_search_roaring", "vs_search_batch", "vs_search_device",
+                 "vs_search", "vs_search_roaring", "vs_search_batch", "vs_search_device", "vs_search_stores",
                  "vs_merge_topk_device", "vs_roaring_to_mask", "vs_cbo_roaring_to_mask"):
         assert must in names
 

@@ -40,42 +40,59 @@ def _destroy_stores(gpu_ctx, category, n=4):
             pass
 
 
+def arroy_key(index, mode, item):
+    """arroy 0.2.0's key as published: index u16 big-endian | mode u8 | item u32 big-endian."""
+    return struct.pack(">HBI", index, mode, item)
+
+
+def arroy_leaf(vector):
+    """An item leaf: tag u8 = 0 | Angular header { norm f32 } | dim x f32 little endian."""
+    norm = float(np.sqrt(np.sum(np.asarray(vector, np.float64) ** 2)))
+    return struct.pack("<Bf", 0, norm) + struct.pack(f"<{len(vector)}f", *vector)
+
+
 def test_existing_index_from_arroy_leaves(gpu_ctx):
+    """The parser is fed bytes it did not write: the pairs are packed here with struct.pack from the
+    published layout and must equal the committed fixture (tests/golden/arroy_leaves.json, written the
+    same way by make_golden.py), tree nodes, metadata and an unknown node mode mixed in. The layout
+    itself is restated, not verified against the crate (arroy is not in the reference tree)."""
     from search_engine_amd import abi
-    category = 7
-    pairs = []
-    for docid, vectors in DOCS.items():
-        for k, v in enumerate(vectors):  # the j-th vector of a document lives in index (category << 8) | j
-            pairs.append(abi.arroy_encode_item((category << 8) | k, docid, v))
-    # what else a cursor over the database yields: tree nodes, metadata, another embedder's items
-    tree_key = bytes([category, 0, 1, 0, 0, 0, 9])
-    meta_key = bytes([category, 0, 2, 0, 0, 0, 0])
-    pairs += [(tree_key, bytes([2]) + bytes(20)), (meta_key, b"\x03\x00\x00\x00angular")]
-    pairs.append(abi.arroy_encode_item((9 << 8) | 0, 1, [1, 1, 1]))
-    pairs.sort()  # LMDB order
+    leaves = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "arroy_leaves.json")))
+    category = leaves["category"]
+    pairs = [(bytes.fromhex(k), bytes.fromhex(v)) for k, v in leaves["pairs"]]
+    packed = [(arroy_key((category << 8) | j, 0, docid), arroy_leaf(v))
+              for docid, vectors in DOCS.items() for j, v in enumerate(vectors)]
+    assert sorted(packed) == [p for p in pairs if p[0][0] == category and p[0][2] == 0]
+    assert pairs == sorted(pairs)  # LMDB order
+    want = leaves["expect"]
     stores = [gpu_ctx.create_store((category << 8) | k, 3, 64) for k in range(3)]
     try:
-        assert gpu_ctx.ingest_arroy_items(pairs) == (6, 2, 1)
+        assert gpu_ctx.ingest_arroy_items(pairs) == (want["n_items"], want["n_other_nodes"], want["n_unrouted"])
         for s in stores:
             s.seal()
-        assert [len(s) for s in stores] == [3, 2, 1]
-        for k, want in enumerate(GOLDEN["stores"]):
+        assert [len(s) for s in stores] == want["store_lens"]
+        for k, want_k in enumerate(GOLDEN["stores"]):
             ids, dist = stores[k].search(np.array(GOLDEN["query"], np.float32), 10)
-            assert ids.tolist() == [e["docid"] for e in want]
-            assert dist == pytest.approx([e["distance"] for e in want], abs=1e-6)
+            assert ids.tolist() == [e["docid"] for e in want_k]
+            assert dist == pytest.approx([e["distance"] for e in want_k], abs=1e-6)
+            for e in want_k:
+                assert stores[k].item_vector(e["docid"]).tolist() == e["vector"]
         _check_emission(_search(gpu_ctx, category, "manual", [0, 1, 2]), GOLDEN["emission"])
         _check_emission(_search(gpu_ctx, category, "manual", [1, 2]), GOLDEN["emission_filtered_1_2"])
-        # a leaf of the wrong dimension, and bytes that are no leaf
-        key, leaf = abi.arroy_encode_item((category << 8) | 0, 5, [1, 2, 3, 4])
+        # a leaf of the wrong dimension, bytes that are no leaf, a short key: every pair is checked
+        # before the first upload, so the good pair in front of the bad one changes nothing either
+        good = (arroy_key(category << 8, 0, 40), arroy_leaf([7, 7, 7]))
+        key = arroy_key(category << 8, 0, 5)
         with pytest.raises(abi.VsError) as e:
-            gpu_ctx.ingest_arroy_items([(key, leaf)])
+            gpu_ctx.ingest_arroy_items([good, (key, arroy_leaf([1, 2, 3, 4]))])
         assert e.value.code == abi.VS_E_DIM_MISMATCH and (e.value.expected, e.value.received) == (3, 4)
         with pytest.raises(abi.VsError) as e:
-            gpu_ctx.ingest_arroy_items([(key, bytes([1]) + leaf[1:])])
+            gpu_ctx.ingest_arroy_items([good, (key, bytes([1]) + arroy_leaf([1, 2, 3])[1:])])
         assert e.value.code == abi.VS_E_FORMAT
         with pytest.raises(abi.VsError) as e:
-            gpu_ctx.ingest_arroy_items([(key[:6], leaf)])
+            gpu_ctx.ingest_arroy_items([good, (key[:6], arroy_leaf([1, 2, 3]))])
         assert e.value.code == abi.VS_E_FORMAT
+        assert stores[0].writer_len() == 3 and not stores[0].contains(40)
     finally:
         for s in stores:
             s.destroy()

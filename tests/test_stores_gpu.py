@@ -1,0 +1,90 @@
+"""vs_search_stores: the whole store loop of VectorSort::fill_buffer
+(src/search/ranking/vector_sort.rs:55-78) in one call. A document's j-th vector lives in store
+(embedder << 8) | j; the call searches every store of the embedder under one filter that crosses to
+the device once, and returns the stores' lists merged by (distance, docid, store). It must equal the
+loop over vs_search it replaces bit for bit, exact ties across stores included."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import facet_mask, synthetic_vectors
+
+pytestmark = pytest.mark.gpu
+
+
+def _loop(stores, query, k, search):
+    """What fill_buffer builds: every store's list, concatenated in store order and sorted by
+    (distance, docid) with a stable sort, NaN last."""
+    hits = []
+    for j, st in enumerate(stores):
+        ids, dist = search(st, query, k)
+        hits += [(float(d), int(i), j, d) for i, d in zip(ids, dist)]
+    hits.sort(key=lambda h: (math.isnan(h[0]), h[0], h[1]))
+    return ([h[1] for h in hits], np.array([h[3] for h in hits], np.float32), [h[2] for h in hits])
+
+
+@pytest.mark.parametrize("n_stores,dtype_name", [(3, "f32"), (17, "f32"), (3, "bin1")])
+def test_all_stores_in_one_call_equal_the_loop_over_stores(gpu_ctx, n_stores, dtype_name):
+    from search_engine_amd import abi
+    dtype, metric = (abi.VS_BIN1, abi.VS_HAMMING) if dtype_name == "bin1" else (abi.VS_F32, abi.VS_ANGULAR)
+    category, n, dim, k = 21, 6000, 128, 10
+    rng = np.random.default_rng(5)
+    stores = []
+    try:
+        first_have = first_rows = None
+        for j in range(n_stores):
+            # "vectors packed in the first writers": store j holds the documents with more than j vectors;
+            # later stores are smaller, and every other one has a smaller capacity than the first
+            have = rng.choice(n, max(40, n // (j + 1)), replace=False).astype(np.uint32)
+            have = np.unique(np.concatenate([have, np.array([7, 8] if j == 0 else [7, 9], np.uint32)]))
+            rows = synthetic_vectors(have.size, dim, 100 + j)
+            if j == 0:
+                first_have, first_rows = have, rows
+            else:
+                # exact ties across stores: document 7's vector j equals its vector 0 (same distance, same
+                # docid: the store decides), and document 9's vector j equals document 8's vector 0 (same
+                # distance, different docids: the docid decides)
+                rows[np.searchsorted(have, 7)] = first_rows[np.searchsorted(first_have, 7)]
+                rows[np.searchsorted(have, 9)] = first_rows[np.searchsorted(first_have, 8)]
+            cap = n if j % 2 == 0 else int(have.max()) + 1
+            st = gpu_ctx.create_store((category << 8) | j, dim, cap, dtype=dtype, metric=metric)
+            stores.append(st)
+            st.upload(have, rows)
+            st.seal()
+        queries = [first_rows[np.searchsorted(first_have, 7)], first_rows[np.searchsorted(first_have, 8)],
+                   synthetic_vectors(1, dim, 77)[0]]
+        mask = facet_mask(n, 30)
+        mask[0] |= np.uint64((1 << 7) | (1 << 8) | (1 << 9))  # the planted documents stay candidates
+        handle = stores[0].create_mask(mask)
+        roaring = abi.mask_to_roaring(mask)
+        for q in queries:
+            for kk in (k, 1, 150):
+                want = _loop(stores, q, kk, lambda st, q, kk: st.search(q, kk))
+                ids, dist, src, ns = gpu_ctx.search_stores(category << 8, q, kk)
+                assert ns == n_stores
+                assert ids.tolist() == want[0] and dist.tobytes() == want[1].tobytes() and src.tolist() == want[2]
+            want = _loop(stores, q, k, lambda st, q, kk: st.search(q, kk, mask))
+            for kwargs in ({"mask": mask}, {"roaring_bytes": roaring}, {"mask_handle": handle}):
+                ids, dist, src, ns = gpu_ctx.search_stores(category << 8, q, k, **kwargs)
+                assert ids.tolist() == want[0] and dist.tobytes() == want[1].tobytes() and src.tolist() == want[2], kwargs
+        # the planted ties really are in the lists, in the order (distance, docid, store)
+        ids, dist, src, _ = gpu_ctx.search_stores(category << 8, queries[0], k)
+        assert ids[:n_stores].tolist() == [7] * n_stores and src[:n_stores].tolist() == list(range(n_stores))
+        ids, dist, src, _ = gpu_ctx.search_stores(category << 8, queries[1], k)
+        assert ids[:n_stores].tolist() == [8] + [9] * (n_stores - 1) and len(set(dist[:n_stores].tolist())) == 1
+        # too little room: the error says so, nothing is written beyond the buffers
+        with pytest.raises(abi.VsError) as err:
+            gpu_ctx.search_stores(category << 8, queries[2], k, cap=k * n_stores - 1)
+        assert err.value.code == abi.VS_E_CAPACITY
+        # the wrong dimension is the reference's InvalidVecDimension, whichever store reports it
+        with pytest.raises(abi.VsError) as err:
+            gpu_ctx.search_stores(category << 8, np.zeros(dim + 1, np.float32), k)
+        assert err.value.code == abi.VS_E_DIM_MISMATCH and (err.value.expected, err.value.received) == (dim, dim + 1)
+        # an embedder without stores: no reader opens, no result, no error
+        ids, dist, src, ns = gpu_ctx.search_stores(99 << 8, queries[2], k)
+        assert ns == 0 and ids.size == 0
+        stores[0].destroy_mask(handle)
+    finally:
+        for st in stores:
+            st.destroy()

@@ -135,7 +135,8 @@ def test_arroy_key_and_leaf_layout():
     assert leaf == bytes([0]) + struct.pack("<f", 5.0) + struct.pack("<2f", 3.0, 4.0)  # tag | norm | vector
     assert abi.arroy_parse_key(key) == (0x0102, 0, 0x0A0B0C0D)
     assert abi.arroy_parse_key(bytes([0, 5, 2, 0, 0, 0, 0])) == (5, 2, 0)  # a metadata key
-    for bad in (b"", bytes(6), bytes(8), bytes([0, 0, 3, 0, 0, 0, 0])):
+    assert abi.arroy_parse_key(bytes([0, 0, 3, 0, 0, 0, 0])) == (0, 3, 0)  # a mode of another arroy version: handed back
+    for bad in (b"", bytes(6), bytes(8)):
         with pytest.raises(abi.VsError) as e:
             abi.arroy_parse_key(bad)
         assert e.value.code == abi.VS_E_FORMAT
