@@ -244,7 +244,8 @@ def main():
     gen.manual_seed(0xC0FFEE + rank)
     stream = torch.cuda.current_stream().cuda_stream
     chunk = 1 << 18
-    sample = None
+    sample_parts, sample_rows = [], 0  # rank 0 keeps the first --cpu-sample-rows rows for the CPU baseline
+    want_sample = rank == 0 and world == 1 and not args.no_cpu_baseline
     for lo in range(0, n_local, chunk):
         m = min(chunk, n_local - lo)
         if bin1:  # uniform random bits = the sign bits of an N(0,1) draw, packed
@@ -258,10 +259,14 @@ def main():
             tdtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
             rows = torch.randn(m, dim, generator=gen, device=dev, dtype=torch.float32).to(tdtype)
         store.upload_device(first + lo, rows.data_ptr(), m, stream)
-        if rank == 0 and lo == 0:
-            sample = rows
+        if want_sample and sample_rows < args.cpu_sample_rows:
+            part = rows[: args.cpu_sample_rows - sample_rows]
+            sample_parts.append(part)
+            sample_rows += part.shape[0]
         torch.cuda.synchronize()
     store.seal()
+    sample = torch.cat(sample_parts) if sample_parts else None
+    del sample_parts
 
     qgen = torch.Generator(device=dev)
     qgen.manual_seed(42)
@@ -347,9 +352,12 @@ def main():
         assert (np.diff(d[j, : cnt[j]]) >= 0).all(), "results not ascending"
 
     def single_query_roofline(r):
-        """The scan reads every passing row once per query: rows + norms + the mask words."""
-        algo = r["n_pass"] * (row_bytes + norm_bytes) + n_slots // 8
-        ms = r["step_kernel_ms"] / n_q  # per scan launch, its share of the merge and gather launches included
+        """The scan reads every passing row once per query: rows + norms + the mask words. One scan
+        launch takes all n_q queries of a step (no row read is shared between them), so a launch's
+        algorithmic bytes are n_q times a query's, and its duration is the step's (the one merge launch
+        and, with more than one rank, the gather included)."""
+        algo = n_q * (r["n_pass"] * (row_bytes + norm_bytes) + n_slots // 8)
+        ms = r["step_kernel_ms"]
         return algo, ms, algo / (ms * 1e-3) / 1e9
 
     sweep = []
@@ -357,7 +365,8 @@ def main():
         for p in [int(x) for x in args.sweep.split(",") if x]:
             r = run(p, max(2, args.steps // 2), 1)
             algo, ms, gbps = single_query_roofline(r)
-            sweep.append({"pass_percent": p, "qps": round(r["qps"], 2), "scan_ms": round(ms, 4),
+            sweep.append({"pass_percent": p, "qps": round(r["qps"], 2), "launch_ms": round(ms, 4),
+                          "ms_per_query": round(ms / n_q, 4),
                           "achieved_gbps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4),
                           "algorithmic_bytes_per_launch": algo})
 
@@ -379,11 +388,20 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(torch, np, sample, queries, args, dim, k)
+        if sweep and not bin1:  # the same baseline beside one filtered sweep point
+            p = 10 if any(e["pass_percent"] == 10 for e in sweep) else sweep[0]["pass_percent"]
+            cpu["filtered"] = cpu_baseline(torch, np, sample, queries, args, dim, k, pass_percent=p,
+                                           mask_words=device_mask(torch, first, n_slots, p, dev), seconds=5.0)
 
     if rank == 0:
+        stale = []  # recorded traffic that was measured on other kernel sources than the ones running now
+
         def recorded_traffic(pass_percent):
             """HBM bytes per scan launch from the committed rocprofv3 --pmc FETCH_SIZE pass of this
-            workload (profiles/scan_traffic*.json, written by tools/profile_summary.py), or None."""
+            workload (profiles/scan_traffic*.json, written by tools/profile_summary.py), or None. The
+            counters need a run of their own under the profiler, so they are never collected inside a
+            benchmark run; the file records a hash of the kernel sources it was measured on, and a
+            number from other sources is reported with `traffic_stale`."""
             sfx = "" if pass_percent == 100 else f"_p{pass_percent}"
             name = "scan_traffic" if args.dtype == "f32" else f"scan_traffic_{args.dtype}"
             tpath = os.path.join(ROOT, "profiles", f"{name}{sfx}.json")
@@ -392,8 +410,13 @@ def main():
             with open(tpath) as f:
                 t = json.load(f)
             same = (t.get("docs") == args.docs and t.get("dtype") == args.dtype and t.get("n_gpus") == world
-                    and t.get("pass_percent") == pass_percent and t.get("dim", dim) == dim)
-            return t.get("hbm_bytes_per_launch") if same else None
+                    and t.get("pass_percent") == pass_percent and t.get("dim", dim) == dim
+                    and t.get("queries_per_launch", 1) == n_q and t.get("k", k) == k)
+            if not same:
+                return None
+            if t.get("csrc_sha256") != csrc_sha256():
+                stale.append(pass_percent)
+            return t.get("hbm_bytes_per_launch")
 
         def recorded_batch_traffic():
             """The same for one batched bf16 call (every kernel of it), profiles/scan_traffic_bf16_batch256.json."""
@@ -432,12 +455,18 @@ def main():
             line["roofline"] = {
                 "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": recorded_traffic(args.pass_percent),
-                "kernel": f"{kernel} (+ its share of the step's merge launch)",
-                "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(ms, 4),
+                "traffic_stale": None,
+                "kernel": (f"{kernel}: ONE launch for the step's {n_q} queries (+ the step's one merge launch)"
+                           if group is not None else
+                           f"{kernel}: {n_q} launches per step (vs_search_device per query; the library's group could not be made)"),
+                "queries_per_launch": n_q, "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(ms, 4),
+                "algorithmic_bytes_per_query": algo // n_q, "ms_per_query": round(ms / n_q, 4),
                 "measured_copy_gbps": round(copy_gbps, 1), "frac_of_measured_copy": round(gbps / copy_gbps, 4),
             }
             for entry in sweep:
                 entry["traffic"] = recorded_traffic(entry["pass_percent"])
+                entry["traffic_stale"] = entry["pass_percent"] in stale
+            line["roofline"]["traffic_stale"] = args.pass_percent in stale
         else:
             line["metric"] = f"batched top-{k} vector QPS, {n_q} queries per step sharing passes over the rows"
             ms = head["step_kernel_ms"]
@@ -483,47 +512,66 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(torch, np, sample, queries, args, dim, k):
+def csrc_sha256():
+    """Hash of the kernel and runtime sources (search_engine_amd/csrc): names a build for the
+    recorded-traffic check. (The tree travels to the GPU box without its .git, so a git tree hash
+    cannot be asked for there; this is the same information from the files themselves.)"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "search_engine_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")) or name == "Makefile":
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
+def cpu_baseline(torch, np, sample, queries, args, dim, k, pass_percent=100, mask_words=None, seconds=10.0):
     """Times the CPU oracle (kind "port": the build's restatement of the reference's exact path;
     the reference itself cannot be built here) on the first rows of the same synthetic set, one
-    query per thread on min(16, cores) threads, and scales to the full row count."""
+    query per thread on min(16, cores) threads, and scales to the full row count. With mask_words
+    (the device mask of a sweep point) the same under that filter."""
     from oracle import scan as oracle
     n = min(args.cpu_sample_rows, sample.shape[0])
+    mask = None
+    if mask_words is not None:
+        mask = mask_words[: -(-n // 64)].cpu().numpy().view(np.uint64).copy()
     host_cores = os.cpu_count() or 1
     threads = min(16, host_cores)
     if args.dtype == "bin1":
         from concurrent.futures import ThreadPoolExecutor
         codes = sample[:n].cpu().numpy().view(np.uint64)
         q = queries[: threads * 2].cpu().numpy().view(np.uint64)
-        oracle.hamming_topk(codes, q[0], k)  # warm
+        oracle.hamming_topk(codes, q[0], k, mask=mask)  # warm
         t0 = time.perf_counter()
         reps = 0
         with ThreadPoolExecutor(threads) as pool:  # the C call releases the GIL
             while True:
-                list(pool.map(lambda qq: oracle.hamming_topk(codes, qq, k), q))
+                list(pool.map(lambda qq: oracle.hamming_topk(codes, qq, k, mask=mask), q))
                 reps += 1
-                if time.perf_counter() - t0 > 10.0 or reps >= 200:
+                if time.perf_counter() - t0 > seconds or reps >= 200:
                     break
         dt = time.perf_counter() - t0
         used = threads
         t1 = time.perf_counter()
-        oracle.hamming_topk(codes, q[0], k)
+        oracle.hamming_topk(codes, q[0], k, mask=mask)
         lat = time.perf_counter() - t1
     else:
         rows = sample[:n].to(torch.float32).cpu().numpy()
         q = queries[: threads * 2].cpu().numpy()
         norms = oracle.norms(rows)  # arroy keeps the norm in the leaf header: not part of a query
-        oracle.nns_batch_mt(rows, q[:threads], k, n_threads=threads, norms=norms)  # warm
+        oracle.nns_batch_mt(rows, q[:threads], k, mask=mask, n_threads=threads, norms=norms)  # warm
         t0 = time.perf_counter()
         reps = 0
         while True:
-            _, _, _, used = oracle.nns_batch_mt(rows, q, k, n_threads=threads, norms=norms)
+            _, _, _, used = oracle.nns_batch_mt(rows, q, k, mask=mask, n_threads=threads, norms=norms)
             reps += 1
-            if time.perf_counter() - t0 > 10.0 or reps >= 400:
+            if time.perf_counter() - t0 > seconds or reps >= 4000:
                 break
         dt = time.perf_counter() - t0
         t1 = time.perf_counter()
-        oracle.nns_by_vector(rows, q[0], k, norms=norms)
+        oracle.nns_by_vector(rows, q[0], k, mask=mask, norms=norms)
         lat = time.perf_counter() - t1
     qps_sample = reps * q.shape[0] / dt
     scale = n / args.docs
@@ -533,7 +581,8 @@ def cpu_baseline(torch, np, sample, queries, args, dim, k):
         "cores": int(used),
         "host_cores": host_cores,
         "kind": "port",
-        "sample": f"first {n} of {args.docs} rows, unfiltered, {reps * q.shape[0]} queries in "
+        "pass_percent": pass_percent,
+        "sample": f"first {n} of {args.docs} rows, {'unfiltered' if mask is None else f'facet pass rate {pass_percent}%'}, {reps * q.shape[0]} queries in "
                   f"{dt:.1f} s, one query per thread on {int(used)} of {host_cores} host cores; "
                   f"scaled by {scale:.4f} to {args.docs} rows",
         "single_thread_ms_per_query_scaled": round(1e3 * lat / scale, 1),

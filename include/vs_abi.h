@@ -345,7 +345,12 @@ int32_t vs_search_device(vs_store* s, const void* d_query, uint32_t dim, uint32_
  * streams, or several threads) race; issue them on one stream. The call records
  * no event either (the stream may be under capture), so unlike the other
  * searches it is not tracked by the snapshot rule: have these searches complete
- * before a vs_store_seal that replaces or removes items. */
+ * before a vs_store_seal that replaces or removes items. A CAPTURED call holds
+ * the store's buffers as they were when it was captured (the present bitmap of
+ * that seal, the slab's address, its size): a graph that contains it is valid
+ * until the next vs_store_seal or vs_store_reserve on the store and must be
+ * captured again after either; the query and the mask are read at their
+ * addresses on every replay, so their contents may change between replays. */
 #define VS_NOALLOC_SCRATCH_BYTES (1u << 20)
 int32_t vs_search_device_noalloc(vs_store* s, const void* d_query, uint32_t dim, uint32_t k,
                                  const uint64_t* d_mask_words, uint64_t* d_out_keys,

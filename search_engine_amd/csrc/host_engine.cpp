@@ -3,6 +3,7 @@
 #include "host_engine.h"
 
 #include <cstdlib>
+#include <unordered_map>
 
 #include <algorithm>
 #include <charconv>
@@ -1150,15 +1151,28 @@ std::map<std::string, uint8_t> assign_embedder_category_ids(const std::vector<st
 }
 
 namespace {
+// arroy::Writer over a vs_store. The indexer hands over items one at a time
+// (typed_chunk.rs:618,650,668,691,701); sending each as an upload of its own costs a transfer and a
+// stream wait per vector, so the writer keeps the pending changes on the host -- per docid its
+// final state, an added row or a removal -- and hands them to the store in ONE vs_store_remove and
+// ONE vs_store_upload when it is built (or when the pending rows pass 64 MiB). Reads of the writer's
+// view are answered from the pending changes first: contains_item and item_vector see an item
+// added a moment ago without anything being sent.
 class GpuWriter : public Writer {
    public:
     GpuWriter(vs_ctx* ctx, uint16_t index, uint32_t dimension, uint64_t capacity)
-        : ctx_(ctx), index_(index), dimension_(dimension), capacity_(capacity) {}
+        : ctx_(ctx), index_(index), dimension_(dimension), capacity_(capacity) {
+        static const bool each = getenv("VS_MIRROR_WRITE_EACH") != nullptr;  // measurement switch: no batching
+        flush_every_change_ = each;
+    }
     ~GpuWriter() override = default;  // stores belong to the context
 
     bool del_item(DocumentId docid) override {
         if (!contains_item(docid)) return false;
-        check(vs_store_remove(store_, &docid, 1));
+        auto it = pending_.find(docid);
+        if (it != pending_.end() && it->second != REMOVED) free_rows_.push_back(it->second);
+        pending_[docid] = REMOVED;
+        changed();
         return true;
     }
     void add_item(DocumentId docid, const std::vector<float>& vector) override {
@@ -1167,49 +1181,111 @@ class GpuWriter : public Writer {
                         "Invalid vector dimensions: expected: `" + std::to_string(dimension_) + "`, found: `" +
                             std::to_string(vector.size()) + "`.",
                         dimension_, (uint32_t)vector.size());
-        if (!store_) {
-            // an index built by an earlier run already has its store
-            if (vs_store_open(ctx_, index_, &store_) != VS_OK) {
-                store_ = nullptr;
-                check(vs_store_create(ctx_, index_, dimension_, VS_F32, VS_ANGULAR, 0, capacity_, &store_));
-            }
+        auto it = pending_.find(docid);
+        size_t row;
+        if (it != pending_.end() && it->second != REMOVED) {
+            row = it->second;  // add_item twice: the last vector wins
+        } else if (!free_rows_.empty()) {
+            row = free_rows_.back();
+            free_rows_.pop_back();
+        } else {
+            row = rows_.size() / dimension_;
+            rows_.resize(rows_.size() + dimension_);
         }
-        if ((uint64_t)docid >= capacity_) {  // milli hands out ever larger docids
-            while ((uint64_t)docid >= capacity_) capacity_ *= 2;
-            check(vs_store_reserve(store_, capacity_));
-        }
-        check(vs_store_upload(store_, &docid, vector.data(), 1));
+        std::copy(vector.begin(), vector.end(), rows_.begin() + row * dimension_);
+        pending_[docid] = row;
+        changed();
     }
     std::optional<std::vector<float>> item_vector(DocumentId docid) override {
-        if (!contains_item(docid)) return std::nullopt;
+        auto it = pending_.find(docid);
+        if (it != pending_.end()) {
+            if (it->second == REMOVED) return std::nullopt;
+            return std::vector<float>(rows_.begin() + it->second * dimension_,
+                                      rows_.begin() + (it->second + 1) * dimension_);
+        }
+        if (!in_store(docid)) return std::nullopt;
         std::vector<float> out(dimension_);
         check(vs_store_item_vector(store_, docid, out.data()));
         return out;
     }
     bool contains_item(DocumentId docid) override {
-        if (!attach()) return false;
-        int32_t has = 0;
-        check(vs_store_contains(store_, docid, &has));
-        return has != 0;
+        auto it = pending_.find(docid);
+        if (it != pending_.end()) return it->second != REMOVED;
+        return in_store(docid);
     }
     bool is_empty() override {
+        flush();
         if (!attach()) return true;
         uint64_t n = 0;
         check(vs_store_writer_len(store_, &n));
         return n == 0;
     }
     void build() override {
+        flush();
         if (attach()) check(vs_store_seal(store_));
     }
     // The reference does not rebuild a store whose last item was removed, and what arroy then
     // answers from the stale tree over deleted leaves cannot be established here. A slab must
     // not go on returning removed documents, so the emptied store is sealed.
     void publish_if_emptied() override {
+        flush();
         uint64_t sealed = 0;
         if (attach() && vs_store_len(store_, &sealed) == VS_OK && sealed != 0) check(vs_store_seal(store_));
     }
 
    private:
+    static constexpr size_t REMOVED = ~(size_t)0;
+    // Hands the pending changes to the store: the removals in one call, the added rows in one call.
+    void flush() {
+        if (pending_.empty()) return;
+        std::vector<uint32_t> gone, ids;
+        std::vector<float> rows;
+        DocumentId top = 0;
+        for (const auto& kv : pending_) {
+            if (kv.second == REMOVED) {
+                gone.push_back(kv.first);
+            } else {
+                ids.push_back(kv.first);
+                top = std::max(top, kv.first);
+            }
+        }
+        // in docid order: neighbouring slots, and the same order whatever the hash map did
+        std::sort(gone.begin(), gone.end());
+        std::sort(ids.begin(), ids.end());
+        rows.resize(ids.size() * dimension_);
+        for (size_t i = 0; i < ids.size(); ++i) {
+            const size_t row = pending_[ids[i]];
+            std::copy(rows_.begin() + row * dimension_, rows_.begin() + (row + 1) * dimension_,
+                      rows.begin() + i * dimension_);
+        }
+        if (!gone.empty() && attach()) check(vs_store_remove(store_, gone.data(), gone.size()));
+        if (!ids.empty()) {
+            if (!store_) {
+                // an index built by an earlier run already has its store
+                if (vs_store_open(ctx_, index_, &store_) != VS_OK) {
+                    store_ = nullptr;
+                    check(vs_store_create(ctx_, index_, dimension_, VS_F32, VS_ANGULAR, 0, capacity_, &store_));
+                }
+            }
+            if ((uint64_t)top >= capacity_) {  // milli hands out ever larger docids
+                while ((uint64_t)top >= capacity_) capacity_ *= 2;
+                check(vs_store_reserve(store_, capacity_));
+            }
+            check(vs_store_upload(store_, ids.data(), rows.data(), ids.size()));
+        }
+        pending_.clear();
+        rows_.clear();
+        free_rows_.clear();
+    }
+    void changed() {
+        if (flush_every_change_ || rows_.size() * sizeof(float) >= (64u << 20)) flush();
+    }
+    bool in_store(DocumentId docid) {
+        if (!attach()) return false;
+        int32_t has = 0;
+        check(vs_store_contains(store_, docid, &has));
+        return has != 0;
+    }
     bool attach() {
         if (!store_ && vs_store_open(ctx_, index_, &store_) != VS_OK) store_ = nullptr;
         return store_ != nullptr;
@@ -1222,6 +1298,10 @@ class GpuWriter : public Writer {
     uint32_t dimension_;
     uint64_t capacity_;
     vs_store* store_ = nullptr;
+    bool flush_every_change_ = false;
+    std::unordered_map<DocumentId, size_t> pending_;  // docid -> row of rows_, or REMOVED
+    std::vector<float> rows_;                         // pending rows, dimension_ floats each
+    std::vector<size_t> free_rows_;                   // rows of rows_ given up by a removal
 };
 }  // namespace
 

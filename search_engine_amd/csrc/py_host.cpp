@@ -3,6 +3,8 @@
 // host_engine.cpp (or keeps its own Rust code) and calls the C ABI directly.
 #include <pybind11/functional.h>
 #include <pybind11/numpy.h>
+#include <chrono>
+
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
@@ -413,6 +415,29 @@ PYBIND11_MODULE(_host, m) {
         if (py::isinstance<GpuWriters>(writers)) return write_vector_points(writers.cast<GpuWriters&>(), p);
         PyWriters w(writers);
         write_vector_points(w, p);
+    });
+    // Measurement hook: the write path for `n_docs` synthetic documents (one generated embedding each,
+    // every 16th document two) as ONE chunk through write_vector_points and the build loop over
+    // GpuWriters; returns the seconds the two calls took (generating the vectors is not timed).
+    m.def("time_write_path", [](GpuWriters& writers, uint32_t dim, uint32_t n_docs) {
+        VectorPoints p;
+        p.embeddings.reserve(n_docs);
+        uint32_t s = 0x9E3779B9u;
+        for (uint32_t d = 0; d < n_docs; ++d) {
+            std::vector<std::vector<float>> vecs(d % 16 == 0 ? 2 : 1, std::vector<float>(dim));
+            for (auto& v : vecs)
+                for (float& x : v) {
+                    s ^= s << 13;
+                    s ^= s >> 17;
+                    s ^= s << 5;
+                    x = (float)(int32_t)s * (1.0f / 2147483648.0f);
+                }
+            p.embeddings.emplace_back(d, std::move(vecs));
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        write_vector_points(writers, p);
+        build_vector_stores(writers);
+        return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     });
     m.def("build_vector_stores", [](py::object writers) {
         if (py::isinstance<GpuWriters>(writers)) return build_vector_stores(writers.cast<GpuWriters&>());

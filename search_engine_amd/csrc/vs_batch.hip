@@ -1484,7 +1484,7 @@ BatchPlan plan_batch(const SlabView& s, uint32_t k) {
     if (!(p.sample_stride & 1)) p.sample_stride -= 1;
     p.blocks1 = p.sample_tiles < 1 ? 1 : p.sample_tiles;
     const uint32_t rest = p.n_tiles - p.sample_tiles;
-    p.blocks2 = rest > 256 ? 256 : rest;
+    p.blocks2 = rest > device_cus() ? device_cus() : rest;  // one persistent workgroup per CU
     size_t off = (size_t)BN * p.ksteps * BK * 2;
     p.off_qnorm = off;
     off += (size_t)BN * 4 + 128;
@@ -1494,7 +1494,7 @@ BatchPlan plan_batch(const SlabView& s, uint32_t k) {
     off += (size_t)BN * p.blocks1 * k * 8;
     p.off_partial2 = off;
     p.in_place = p.ksteps >= 3;
-    p.fallback_blocks = p.n_tiles < 256 ? p.n_tiles : 256;
+    p.fallback_blocks = p.n_tiles < device_cus() ? p.n_tiles : device_cus();
     {
         const uint32_t lists = p.in_place && p.fallback_blocks > p.blocks2 + 1 ? p.fallback_blocks : p.blocks2 + 1;
         off += (size_t)BN * lists * k * 8;

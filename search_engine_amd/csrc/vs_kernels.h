@@ -33,6 +33,11 @@ struct ScanTuning {
     int32_t query_lanes = 0;     // many-query launches: queries in flight per share of the mask words, 0 = default (1)
 };
 
+// Compute units the default grids are sized for (256 until vs_init has asked the device). One value
+// per process: every GPU of a node is the same part.
+void set_device_cus(uint32_t n);
+uint32_t device_cus();
+
 uint32_t scan_grid_blocks(const SlabView& s, const ScanTuning& t, bool masked);
 // device bytes of the partial-list buffer one scan of this slab writes
 uint64_t scan_partial_bytes(const SlabView& s, uint32_t k, const ScanTuning& t);

@@ -27,7 +27,10 @@ namespace vs {
 
 constexpr int WAVES = 4;               // waves per workgroup
 constexpr int QCAP = 128 + 64;         // row queue entries per wave: the largest scoring group + one mask word
-constexpr uint32_t NUM_CUS = 256;       // MI355X
+// Compute units of the device the grids are sized for: 256 on a whole MI355X; vs_init reports what
+// the runtime sees (a partitioned or CU-masked device has fewer).
+static uint32_t g_num_cus = 256;
+#define NUM_CUS g_num_cus
 
 struct ScanArgs {
     const u32x4* rows;
@@ -1672,6 +1675,11 @@ uint32_t scan_grid_blocks(const SlabView& s, const ScanTuning& t, bool masked) {
     const uint64_t cap = (s.row_vecs <= 64 ? 4 : 2) * NUM_CUS;
     return (uint32_t)(want < 1 ? 1 : want > cap ? cap : want);
 }
+
+void set_device_cus(uint32_t n) {
+    if (n >= 1 && n <= 1024) g_num_cus = n;
+}
+uint32_t device_cus() { return g_num_cus; }
 
 uint64_t scan_partial_bytes(const SlabView& s, uint32_t k, const ScanTuning& t) {
     uint32_t m = 0;

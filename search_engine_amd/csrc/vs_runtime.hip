@@ -615,6 +615,7 @@ extern "C" int32_t vs_init(int32_t device_ordinal, vs_ctx** out) {
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(VS_E_DEVICE, "device %d is %s; the kernels are built for gfx950 only",
                     device_ordinal, prop.gcnArchName);
+    vs::set_device_cus((uint32_t)prop.multiProcessorCount);  // grids go by the CUs this process can use
     std::unique_ptr<vs_ctx> ctx(new vs_ctx());
     ctx->device = device_ordinal;
     auto env_int = [](const char* name, int32_t lo, int32_t hi, std::atomic<int32_t>* dst) {

@@ -49,6 +49,20 @@ def test_gpus_n_starts_its_own_ranks(world, dtype):
     _check_ranks(line, world, 100003)
 
 
+@pytest.mark.parametrize("flags,docs", [(["--dtype", "f32"], 10_000_000),
+                                        (["--dtype", "bf16", "--batch-queries", "256"], 10_000_000),
+                                        (["--dtype", "bin1"], 50_000_000)])
+def test_eight_ranks_at_the_benchmark_sizes(flags, docs):
+    """The three commands of the 8-GPU runs (the f32 headline, BASELINE config 3, config 4), at their
+    default sizes, as the driver starts them: eight ranks come up, agree on the world, and their shards
+    tile the documents on multiples of 64."""
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--dry-launch", *flags], env=_clean_env(),
+                         capture_output=True, text=True, timeout=600)
+    line = _one_line(out)
+    assert line["docs"] == docs
+    _check_ranks(line, 8, docs)
+
+
 def test_started_by_torch_distributed_run():
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", "29547", BENCH, "--gpus", "2",

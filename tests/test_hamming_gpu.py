@@ -174,11 +174,12 @@ def test_batch_device_entry_point_on_a_binary_store(gpu_ctx):
         store.destroy()
 
 
-@pytest.mark.parametrize("k", [32, 33, 64, 65, 100, 128])
+@pytest.mark.parametrize("k", [32, 33, 64, 65, 100, 128, 129, 300, 1000])
 @pytest.mark.parametrize("order", ["improving", "worsening", "ties", "random"])
 def test_top_k_lists_filled_in_batches(gpu_ctx, k, order):
     """For 32 < k <= 128 a wave parks candidates and merges 65 or more of them into its list at once
-    (k = 32 inserts one at a time: the same answers). Adversarial arrival orders: every row better
+    (k = 32 inserts one at a time: the same answers); beyond 128 the list lives in LDS and the parked
+    batch is merged into it in place. Adversarial arrival orders: every row better
     than all before it (each one passes the bound, merge after merge), every row worse (nothing
     passes once the list is full), long runs of equal distances (order by docid), and random; under
     no filter, a dense one and one that leaves fewer candidates than k."""

@@ -41,8 +41,13 @@ def test_single_query_bench_under_a_one_rank_rccl_group():
     r = line["roofline"]
     assert r["bound"] == "hbm" and line["config"]["ranks_in_group"] == 1
     # the accounting, not the speed: bytes = passing rows * (row + norm) + mask, rate = bytes / launch time
-    n_pass = (r["algorithmic_bytes_per_launch"] - 300032 // 8) / (768 * 4 + 4)
+    # one scan launch takes the step's 16 queries; no row read is shared, so its bytes are 16 queries' bytes
+    assert r["queries_per_launch"] == 16 and r["algorithmic_bytes_per_launch"] == 16 * r["algorithmic_bytes_per_query"]
+    assert abs(r["ms_per_query"] - r["avg_launch_ms"] / 16) < 1e-3
+    n_pass = (r["algorithmic_bytes_per_query"] - 300032 // 8) / (768 * 4 + 4)
     assert 0.45 * 300000 < n_pass < 0.55 * 300000
+    # no counter pass was recorded for this workload: no traffic, hence nothing stale
+    assert r["traffic"] is None and r["traffic_stale"] is False
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 0.02 * r["achieved"]
     assert abs(r["frac"] - r["achieved"] / 8000.0) < 1e-3 and 0.02 < r["frac"] < 1
 
@@ -51,7 +56,7 @@ def test_hamming_bench_line():
     line = bench("--docs", "2000000", "--dtype", "bin1", force_dist=False)
     r = line["roofline"]
     assert line["config"]["k"] == 100 and line["config"]["dim"] == 1536
-    assert r["algorithmic_bytes_per_launch"] == 2000000 * 192 + 2000000 // 8 and 0.02 < r["frac"] < 1
+    assert r["algorithmic_bytes_per_query"] == 2000000 * 192 + 2000000 // 8 and 0.02 < r["frac"] < 1
 
 
 def test_batched_bench_under_a_one_rank_rccl_group():
@@ -76,3 +81,19 @@ def test_the_exchange_through_torch_distributed_when_the_group_cannot_be_made():
         assert via_torch["config"]["collective"].startswith("torch.distributed")
         assert via_torch["value"] > 0 and 0 < via_torch["roofline"]["frac"] < 1
         assert via_torch["roofline"]["algorithmic_bytes_per_launch"] == via_group["roofline"]["algorithmic_bytes_per_launch"]
+
+
+def test_cpu_baseline_legs_and_the_sample_size():
+    """The CPU leg samples --cpu-sample-rows rows across upload chunks (not just the first chunk), and
+    one sweep point gets the same baseline under its filter."""
+    env = dict(os.environ)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
+                          "--docs", "400000", "--cpu-sample-rows", "300000", "--sweep", "10"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][0])
+    cpu = line["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["pass_percent"] == 100 and "first 300000 of 400000 rows" in cpu["sample"]
+    assert cpu["filtered"]["pass_percent"] == 10 and "facet pass rate 10%" in cpu["filtered"]["sample"]
+    assert cpu["filtered"]["value"] > cpu["value"] > 0  # a tenth of the rows to score
+    assert line["sweep"][0]["pass_percent"] == 10 and line["sweep"][0]["traffic_stale"] is False

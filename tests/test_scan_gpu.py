@@ -138,6 +138,37 @@ def test_parity_k(gpu_ctx, k):
     run_case(gpu_ctx, vectors, q, k, mask=facet_mask(n, 50))
 
 
+@pytest.mark.parametrize("k", [129, 500, 1024])
+@pytest.mark.parametrize("order", ["improving", "worsening", "random"])
+def test_lists_in_lds_filled_in_batches(gpu_ctx, k, order):
+    """Beyond k = 128 (deep pagination: limit = offset + limit, src/search/search.rs:115) a wave's list
+    lives in LDS and takes its keys a batch at a time: up to 128 parked candidates are sorted and merged
+    into the list in place. Adversarial arrival orders: every row closer to the query than all before
+    it (every one passes the bound, merge after merge, each landing in front), every row farther (once
+    the list is full nothing passes), and random; no filter, a dense one, a selective one, and one
+    that leaves fewer candidates than k. Exact ties are planted as well (the docid decides)."""
+    n, dim = 40_000, 64
+    rng = np.random.default_rng(k + len(order))
+    q = rng.standard_normal(dim).astype(np.float32)
+    noise = rng.standard_normal((n, dim)).astype(np.float32)
+    if order == "improving":
+        scale = np.linspace(3.0, 0.01, n)
+    elif order == "worsening":
+        scale = np.linspace(0.01, 3.0, n)
+    else:
+        scale = rng.uniform(0.01, 3.0, n)
+    vectors = (q[None, :] + noise * scale[:, None].astype(np.float32)).astype(np.float32)
+    vectors[30_000:30_040] = vectors[100:140]  # exact ties
+    store = make_store(gpu_ctx, vectors)
+    try:
+        few = np.zeros(n, bool)
+        few[rng.choice(n, k - 7, replace=False)] = True
+        for mask in (None, facet_mask(n, 60), facet_mask(n, 4), oracle.bool_to_mask(few)):
+            run_case(gpu_ctx, vectors, q, k, mask=mask, store=store)
+    finally:
+        store.destroy()
+
+
 def test_k_larger_than_candidates(gpu_ctx):
     n, dim = 500, 64
     vectors = synthetic_vectors(n, dim, 3)

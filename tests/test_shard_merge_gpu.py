@@ -215,3 +215,56 @@ def test_a_step_of_queries_in_one_launch_equals_their_own_searches(gpu_ctx, shap
     finally:
         group.destroy()
         store.destroy()
+
+
+def test_eight_bf16_shards_sharing_passes_equal_the_single_store(gpu_ctx):
+    """BASELINE config 3's data flow on one GPU: eight docid-range shard stores (bf16), on each the
+    batched matrix-core scan of all queries (vs_search_batch_device, what vs_search_sharded_device runs
+    under VS_SHARDED_SHARE_PASSES), the keys laid out [rank][query][k] as the all-gather leaves them, ONE
+    vs_merge_topk_batch_device -- against vs_search_batch_device on one store holding everything. The
+    merge is associative and every shard's list holds its k best, so the ids are the same; distances
+    come from the same products in the same order (a row's score does not depend on its shard)."""
+    from search_engine_amd import abi, sharded
+    world, n, dim, k, n_q = 8, 160_000, 256, 10, 40
+    stream = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(23)
+    rows = torch.randn(n, dim, generator=gen, device=DEV).to(torch.bfloat16)
+    queries = torch.randn(n_q, dim, generator=gen, device=DEV)
+    d_mask = torch.from_numpy(facet_mask(-(-n // 64) * 64, 30).view(np.int64)).to(DEV)
+    whole = gpu_ctx.create_store(840, dim, n, dtype=abi.VS_BF16)
+    shards = []
+    try:
+        whole.upload_device(0, rows.data_ptr(), n, stream)
+        torch.cuda.synchronize()
+        whole.seal()
+        for masked in (True, False):
+            ws = torch.empty(whole.batch_workspace_bytes(k), dtype=torch.uint8, device=DEV)
+            want = torch.zeros(n_q * k, dtype=torch.int64, device=DEV)
+            whole.search_batch_device(queries.data_ptr(), n_q, dim, k, d_mask.data_ptr() if masked else 0,
+                                      ws.data_ptr(), want.data_ptr(), stream)
+            gathered = torch.zeros(world * n_q * k, dtype=torch.int64, device=DEV)
+            for g in range(world):
+                first, count = sharded.shard_range(g, world, n)
+                if len(shards) <= g:
+                    st = gpu_ctx.create_store(841 + g, dim, max(count, 64), dtype=abi.VS_BF16, docid_base=first)
+                    shards.append(st)
+                    st.upload_device(first, rows[first:first + count].data_ptr(), count, stream)
+                    torch.cuda.synchronize()
+                    st.seal()
+                st = shards[g]
+                sws = torch.empty(st.batch_workspace_bytes(k), dtype=torch.uint8, device=DEV)
+                st.search_batch_device(queries.data_ptr(), n_q, dim, k, d_mask[first // 64:].data_ptr() if masked else 0,
+                                       sws.data_ptr(), gathered[g * n_q * k:].data_ptr(), stream)
+                torch.cuda.synchronize()
+            ids, dist, cnt = _merge_on_gpu(gpu_ctx, gathered.cpu().numpy(), world, n_q * k, n_q, k, k, abi.VS_ANGULAR)
+            want_keys = want.cpu().numpy().view(np.uint64).reshape(n_q, k)
+            assert (cnt == k).all()
+            assert ids.tolist() == (want_keys & np.uint64(0xFFFFFFFF)).astype(np.uint32).tolist(), masked
+            hi = (want_keys >> np.uint64(32)).astype(np.uint32)
+            bits = np.where(hi & np.uint32(0x80000000), hi & np.uint32(0x7FFFFFFF), ~hi)
+            assert dist.view(np.uint32).tolist() == bits.tolist()
+    finally:
+        whole.destroy()
+        for st in shards:
+            st.destroy()

@@ -108,3 +108,40 @@ def test_binary_store_and_the_size_limit(gpu_ctx):
         assert e.value.code == abi.VS_E_CAPACITY and "scratch" in e.value.message
     finally:
         store.destroy()
+
+
+def test_noalloc_search_under_graph_capture(gpu_ctx):
+    """What the entry point is for: a caller under HIP graph capture. The call is captured once and
+    replayed; a replay reads the query and the mask where they lay at capture and the store as it was
+    registered then, so it stays valid until the next vs_store_seal or vs_store_reserve (documented in
+    include/vs_abi.h) -- here the store does not change, the query's contents do."""
+    dev = torch.device("cuda", 0)
+    n, dim, k = 50_000, 96, 10
+    rows = synthetic_vectors(n, dim, 21)
+    store = gpu_ctx.create_store(910, dim, n)
+    try:
+        store.upload(np.arange(n, dtype=np.uint32), rows)
+        store.seal()
+        queries = torch.from_numpy(synthetic_vectors(3, dim, 22)).to(dev)
+        d_q = queries[0].clone()
+        d_mask = torch.from_numpy(facet_mask(n, 30).view(np.int64)).to(dev)
+        keys = torch.zeros(k, dtype=torch.int64, device=dev)
+        ws = torch.empty(store.workspace_bytes(k), dtype=torch.uint8, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side, capture_error_mode="relaxed"):
+            store.search_device_noalloc(d_q.data_ptr(), dim, k, d_mask.data_ptr(), keys.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream)
+        for j in range(3):
+            d_q.copy_(queries[j])
+            keys.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            want = torch.zeros(k, dtype=torch.int64, device=dev)
+            store.search_device(queries[j].data_ptr(), dim, k, d_mask.data_ptr(), ws.data_ptr(), want.data_ptr(),
+                                torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert keys.cpu().tolist() == want.cpu().tolist(), j
+    finally:
+        store.destroy()

@@ -18,8 +18,11 @@ import glob
 import json
 import os
 import statistics
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (csrc_sha256)
 
 
 def find(d, suffix):
@@ -40,6 +43,9 @@ def main():
     ap.add_argument("--pass-percent", type=int, default=100)
     ap.add_argument("--n-gpus", type=int, default=1)
     ap.add_argument("--kernel", default="scan_angular_kernel")
+    ap.add_argument("--queries-per-launch", type=int, default=16,
+                    help="queries one scan launch takes (bench.py --queries-per-step)")
+    ap.add_argument("--k", type=int, default=None)
     args = ap.parse_args()
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
@@ -76,6 +82,10 @@ def main():
             "fetch_size_kib_mean": mean_kib,
             "correction": "x1024 (KiB) x2 (gfx950: FETCH_SIZE counts 128-B requests as 64 B)",
             "hbm_bytes_per_launch": int(mean_kib * 1024 * 2),
+            "queries_per_launch": args.queries_per_launch,
+            "k": args.k if args.k is not None else (100 if args.dtype == "bin1" else 10),
+            # the kernel sources the counters were collected on (bench.py reports other sources as stale)
+            "csrc_sha256": bench.csrc_sha256(),
             "source": f"rocprofv3 --pmc FETCH_SIZE, profiles/{args.tag}_pmc_fetch_size.csv",
         }
         # the headline (p = 100 %) keeps the plain names; other pass rates get a suffix
