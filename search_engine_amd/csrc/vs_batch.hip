@@ -993,6 +993,10 @@ __global__ __launch_bounds__(BTHREADS) void scan_batch_stream_kernel(StreamArgs 
             multiply(Int<0>{}, fa[1], fb[0]);
             __builtin_amdgcn_sched_barrier(0);
             // my pieces of the next step are in LDS, my reads of this one are done ...
+            // (Measured again on this rotated loop and dropped: one LDS-DMA dword per line three or five steps
+            // ahead, kept out of the wait by vmcnt(1), so that the step's own requests hit L2 -- 3.92 / 3.99 ms
+            // against 3.52 ms in a same-box A/B. The loop does not wait for HBM; one more memory instruction
+            // per wave and step costs more than the earlier arrival gains.)
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             // ... everyone's are

@@ -59,10 +59,12 @@ def main():
             for r in csv.DictReader(f):
                 if "vs::" in r["Kernel_Name"]:
                     name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-                    by[(name, int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]))].append(
+                    wgs = int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])
+                    lanes = int(r.get("Grid_Size_Y") or 1) // int(r.get("Workgroup_Size_Y") or 1)
+                    by[(name, f"{wgs} x {lanes}" if lanes > 1 else str(wgs))].append(
                         (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
         with open(os.path.join(out, f"{args.tag}_scan_by_grid.txt"), "w") as f:
-            f.write("kernel | workgroups | launches | min us | median us | mean us | max us\n")
+            f.write("kernel | workgroups (x query lanes) | launches | min us | median us | mean us | max us\n")
             for (name, wgs), v in sorted(by.items()):
                 f.write(f"{name} | {wgs} | {len(v)} | {min(v):.1f} | {statistics.median(v):.1f} | "
                         f"{statistics.mean(v):.1f} | {max(v):.1f}\n")
