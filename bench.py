@@ -428,7 +428,11 @@ def main():
                 t = json.load(f)
             same = (t.get("docs") == args.docs and t.get("dim") == dim and t.get("n_gpus") == world
                     and t.get("pass_percent") == args.pass_percent and t.get("batch_queries") == n_q)
-            return t.get("hbm_bytes_per_launch") if same else None
+            if not same:
+                return None
+            if t.get("csrc_sha256") != csrc_sha256():
+                stale.append(args.pass_percent)
+            return t.get("hbm_bytes_per_launch")
 
         what = {"f32": "cosine (arroy Angular)", "bf16": "cosine (arroy Angular)", "bin1": "Hamming"}[args.dtype]
         unit = "bit binary-quantised" if bin1 else f"dim {args.dtype}"
@@ -480,7 +484,7 @@ def main():
                 line["roofline"] = {
                     "bound": "hbm", "achieved": round(algo / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                    "traffic": recorded_batch_traffic(),
+                    "traffic": recorded_batch_traffic(), "traffic_stale": args.pass_percent in stale,
                     "kernel": "scan_batch_bf16_kernel (both passes, merges and the query prologue included)",
                     "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(ms, 4),
                     "mfma_tflops": round(flop / (ms * 1e-3) / 1e12, 1),

@@ -155,7 +155,10 @@ struct NoDenseFn {
 struct EveryWord {
     __device__ __forceinline__ bool keep(uint64_t) const { return true; }
 };
-template <int GROUP, typename ScoreFn, typename DenseFn = NoDenseFn, typename WordFn = EveryWord>
+// ROUNDS > 0: batches with fewer than ROUNDS candidates per non-empty word are unpacked by rounds (below).
+// The code costs a few registers, which the scan over long f32 rows does not have to spare (its four
+// waves per SIMD under a selective filter end at 128): 0 there.
+template <int GROUP, int ROUNDS, typename ScoreFn, typename DenseFn = NoDenseFn, typename WordFn = EveryWord>
 __device__ __forceinline__ void scan_masked_slots(const uint64_t* __restrict__ present,
                                                   const uint64_t* __restrict__ cand,
                                                   uint64_t n_slots, uint32_t w, uint32_t W, int lane,
@@ -176,39 +179,67 @@ __device__ __forceinline__ void scan_masked_slots(const uint64_t* __restrict__ p
         return wd;
     };
     uint32_t qcount = 0;
+    // scores whole groups off the front of the queue and moves the (< GROUP) leftovers there
+    auto drain = [&]() {
+        uint32_t head = 0;
+        do {
+            score(head, (uint32_t)GROUP);
+            head += GROUP;
+        } while (qcount - head >= (uint32_t)GROUP);
+        const uint32_t rem = qcount - head;
+        uint32_t v = 0;
+        if ((uint32_t)lane < rem) v = queue[head + lane];
+        wave_lds_fence();
+        if ((uint32_t)lane < rem) queue[lane] = v;
+        wave_lds_fence();
+        qcount = rem;
+    };
     // (a caller that had to look at the wave's first 64 words anyway hands them over)
     uint64_t wd_next = have_first ? first_batch : fetch_words(0);
     for (uint64_t t0 = 0; t0 < my_words; t0 += 64) {
-        const uint64_t wd = wd_next;
+        uint64_t wd = wd_next;
         if (t0 + 64 < my_words) wd_next = fetch_words(t0 + 64);
-        uint64_t nz = __ballot(wd != 0);
-        while (nz) {
-            const int b = __builtin_ctzll(nz);
-            nz &= nz - 1;
+        // words the kernel takes whole, one at a time
+        uint64_t whole = __ballot(wd != 0 && dense.wants(wd));
+        while (whole) {
+            const int b = __builtin_ctzll(whole);
+            whole &= whole - 1;
+            dense((uint32_t)(((uint64_t)w + (t0 + (uint64_t)b) * W) << 6), readlane_u64(wd, b));
+        }
+        if (dense.wants(wd)) wd = 0;
+        uint64_t live = __ballot(wd != 0);
+        if (!live) continue;
+        // Under a selective filter (fewer than ROUNDS candidates per word with any) the words are unpacked by
+        // all lanes together: in every round each lane that still has a candidate in ITS word appends the
+        // lowest one (ballot + prefix count give it its place), so a batch of 64 words costs as many rounds
+        // as its fullest word holds candidates -- four or so under a 1 % filter, where a walk word by word
+        // took thirty steps. The queue's order is then round-major; which rows share a scoring group
+        // changes nothing in any row's distance or in the set the lists keep. Denser batches keep the walk
+        // word by word: their candidates are neighbours in memory, and reading them in slot order is what
+        // lets a dense scan stream.
+        if (ROUNDS > 0 && wave_sum_u32((uint32_t)__popcll(wd)) < (uint32_t)ROUNDS * (uint32_t)__popcll(live)) {
+            const uint32_t my_slot0 = (uint32_t)(((uint64_t)w + (t0 + (uint64_t)lane) * W) << 6);
+            while (live) {
+                if (wd) {
+                    queue[qcount + lanes_below(live)] = my_slot0 + (uint32_t)__builtin_ctzll(wd);
+                    wd &= wd - 1;
+                }
+                qcount += (uint32_t)__popcll(live);
+                wave_lds_fence();
+                if (qcount >= (uint32_t)GROUP) drain();
+                live = __ballot(wd != 0);
+            }
+            continue;
+        }
+        while (live) {
+            const int b = __builtin_ctzll(live);
+            live &= live - 1;
             const uint64_t word = readlane_u64(wd, b);
             const uint32_t slot0 = (uint32_t)(((uint64_t)w + (t0 + (uint64_t)b) * W) << 6);
-            if (dense.wants(word)) {
-                dense(slot0, word);
-                continue;
-            }
             if ((word >> lane) & 1) queue[qcount + lanes_below(word)] = slot0 + (uint32_t)lane;
             qcount += (uint32_t)__popcll(word);
             wave_lds_fence();
-            if (qcount >= (uint32_t)GROUP) {
-                uint32_t head = 0;
-                do {
-                    score(head, (uint32_t)GROUP);
-                    head += GROUP;
-                } while (qcount - head >= (uint32_t)GROUP);
-                // keep the (< GROUP) leftovers at the front
-                const uint32_t rem = qcount - head;
-                uint32_t v = 0;
-                if ((uint32_t)lane < rem) v = queue[head + lane];
-                wave_lds_fence();
-                if ((uint32_t)lane < rem) queue[lane] = v;
-                wave_lds_fence();
-                qcount = rem;
-            }
+            if (qcount >= (uint32_t)GROUP) drain();
         }
     }
     if (qcount) score(0, qcount);
@@ -441,8 +472,8 @@ __device__ __forceinline__ void scan_float_rows(const ScanArgs& a, unsigned char
         };
 
         if (!idle)
-            scan_masked_slots<U>(present, cand, n_slots, w, W, lane, queue, score_rows, NoDenseFn(), EveryWord(),
-                                 have_first, first_batch);
+            scan_masked_slots<U, (ELEM == VS_BF16 || NCH <= 2) ? 4 : 0>(present, cand, n_slots, w, W, lane, queue, score_rows,
+                                                                NoDenseFn(), EveryWord(), have_first, first_batch);
         finish_block(top, lists, k, wib, lane, a.partial + (uint64_t)y * a.partial_stride);
         // one list buffer only: wave 0 must be through with it before the next query's lists go there
         if (a.list_bufs < 2 && y + y_step < a.n_q) __syncthreads();
@@ -667,7 +698,7 @@ __global__ __launch_bounds__(WAVES * 64) void scan_multi_kernel(MultiArgs m) {
         }
     };
 
-    scan_masked_slots<U>(a.present, a.cand, a.n_slots, w, W, lane, queue, score_rows);
+    scan_masked_slots<U, 0>(a.present, a.cand, a.n_slots, w, W, lane, queue, score_rows);
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         if ((uint32_t)q < m.n_q)
@@ -1008,8 +1039,8 @@ __global__ __launch_bounds__(NW * 64) void scan_mq32_kernel(Mq32Args m) {
 #ifdef VS_MQ_STAMP
     const uint64_t t0 = __builtin_amdgcn_s_memtime(), r0_ = __builtin_amdgcn_s_memrealtime();
 #endif
-    scan_masked_slots<32>(a.present, a.cand, a.n_slots, w, W, lane, queue, score_rows, NoDenseFn(),
-                          Mq32Words{m.words, w});
+    scan_masked_slots<32, 0>(a.present, a.cand, a.n_slots, w, W, lane, queue, score_rows, NoDenseFn(),
+                                 Mq32Words{m.words, w});
 #ifdef VS_MQ_STAMP
     const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1_ = __builtin_amdgcn_s_memrealtime();
     if (blockIdx.x == 7 && threadIdx.x == 0)
@@ -1266,14 +1297,14 @@ __global__ __launch_bounds__(WAVES * 64) void scan_hamming_kernel(HammingArgs a)
                 HammingPairs<NT> pairs{rows, docid_base, lane, &top};
                 pairs.load_query(query);
                 if (!idle)
-                    scan_masked_slots<16 * U>(present, cand, n_slots, w, W, lane, queue, score_rows, pairs,
-                                              EveryWord(), have_first, first_batch);
+                    scan_masked_slots<16 * U, 16>(present, cand, n_slots, w, W, lane, queue, score_rows, pairs,
+                                                    EveryWord(), have_first, first_batch);
                 scanned = true;
             }
         }
         if (!scanned && !idle)
-            scan_masked_slots<16 * U>(present, cand, n_slots, w, W, lane, queue, score_rows, NoDenseFn(),
-                                      EveryWord(), have_first, first_batch);
+            scan_masked_slots<16 * U, 16>(present, cand, n_slots, w, W, lane, queue, score_rows, NoDenseFn(),
+                                            EveryWord(), have_first, first_batch);
         top.merge_parked();
         finish_block(top, lists, k, wib, lane, a.partial + (uint64_t)y * a.partial_stride);
         if (a.list_bufs < 2 && y + y_step < a.n_q) __syncthreads();
@@ -1387,7 +1418,7 @@ __global__ __launch_bounds__(WAVES * 64) void scan_hamming_multi_kernel(HammingM
         }
     };
 
-    scan_masked_slots<16 * U>(a.present, a.cand, a.n_slots, w, W, lane, queue, score_rows);
+    scan_masked_slots<16 * U, 0>(a.present, a.cand, a.n_slots, w, W, lane, queue, score_rows);
 #pragma unroll
     for (int q = 0; q < HQ; ++q) {
         if ((uint32_t)q < m.n_q)

@@ -14,6 +14,8 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (csrc_sha256)
 d, docs, dim, n_q, percent = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 path = max(glob.glob(os.path.join(d, "*", "*_counter_collection.csv")), key=os.path.getmtime)
 per_dispatch = collections.defaultdict(float)
@@ -32,6 +34,7 @@ out = {
     "hbm_bytes_per_launch": int(sum(per_kernel.values())),
     "per_kernel_bytes": {k: int(v) for k, v in per_kernel.items()},
     "correction": "x1024 (KiB) x2 (gfx950: FETCH_SIZE counts 128-B requests as 64 B)",
+    "csrc_sha256": bench.csrc_sha256(),  # the kernel sources the counters were collected on
     "source": "rocprofv3 --pmc FETCH_SIZE -- python3 tools/batch_probe.py --docs %d --pass-percents %d --reps 3; "
               "all kernels of one vs_search_batch_device call, mean of %d calls" % (docs, percent, calls),
 }
