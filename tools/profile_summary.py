@@ -29,7 +29,7 @@ def find(d, suffix):
     hits = glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True)
     if not hits:
         raise SystemExit(f"no *{suffix} under {d}")
-    return hits[0]
+    return max(hits, key=os.path.getmtime)  # (gpurun merges a run's files into what earlier runs left behind)
 
 
 def main():
