@@ -1227,10 +1227,12 @@ class GpuWriter : public Writer {
     // The reference does not rebuild a store whose last item was removed, and what arroy then
     // answers from the stale tree over deleted leaves cannot be established here. A slab must
     // not go on returning removed documents, so the emptied store is sealed.
-    void publish_if_emptied() override {
+    bool publish_if_emptied() override {
         flush();
+        if (!attach()) return false;
         uint64_t sealed = 0;
-        if (attach() && vs_store_len(store_, &sealed) == VS_OK && sealed != 0) check(vs_store_seal(store_));
+        if (vs_store_len(store_, &sealed) == VS_OK && sealed != 0) check(vs_store_seal(store_));
+        return true;
     }
 
    private:
@@ -1380,7 +1382,9 @@ uint32_t build_vector_stores(Writers& writers) {
     for (uint32_t k = 0; k <= 0xFF; ++k) {
         Writer& writer = writers.writer((uint8_t)k);
         if (writer.is_empty()) {
-            writer.publish_if_emptied();
+            // (the writers behind the first empty one hold nothing either: vectors are packed)
+            for (uint32_t e = k; e <= 0xFF && writers.writer((uint8_t)e).publish_if_emptied(); ++e) {
+            }
             break;
         }
         writer.build();

@@ -371,9 +371,12 @@ struct Writer {
     virtual bool is_empty() = 0;
     virtual void build() = 0;
     // Called by the build loop for the first EMPTY writer, which the reference leaves unbuilt
-    // (index_documents/mod.rs:559-561). No counterpart in arroy. A writer over a store that would
-    // otherwise keep answering with the items of its last build publishes its emptiness here.
-    virtual void publish_if_emptied() {}
+    // (index_documents/mod.rs:559-561), and for the writers behind it for as long as one answers true
+    // (a document's vectors are packed in the first writers, so those are empty as well, and a
+    // document that lost its last three vectors empties three writers in one run). No counterpart
+    // in arroy. A writer over a store that would otherwise keep answering with the items of its
+    // last build publishes its emptiness here; the answer is whether such a store exists at all.
+    virtual bool publish_if_emptied() { return false; }
 };
 
 // The 256 writers `(embedder_index << 8) | k` of one embedder.

@@ -164,3 +164,103 @@ def test_write_path_over_gpu_stores(gpu_ctx):
     finally:
         del writers
         _destroy_stores(gpu_ctx, category)
+
+
+class _ListWriter:
+    """A plain in-memory writer (the same fake tests/test_write_path.py drives the mirror with)."""
+
+    def __init__(self):
+        self.items, self.built = {}, {}
+
+    def del_item(self, d):
+        return self.items.pop(d, None) is not None
+
+    def add_item(self, d, v):
+        self.items[d] = [float(x) for x in v]
+
+    def item_vector(self, d):
+        return self.items.get(d)
+
+    def contains_item(self, d):
+        return d in self.items
+
+    def is_empty(self):
+        return not self.items
+
+    def build(self):
+        self.built = dict(self.items)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5])
+def test_random_indexing_runs_leave_the_stores_a_plain_writer_would(gpu_ctx, seed):
+    """The mirror's writers over GPU stores buffer a chunk's changes and hand them over in one upload
+    (and must flush whenever the chunk reads its own writes back: typed_chunk.rs:618-707 deletes an
+    item, looks vectors up by value and re-adds them inside one transaction). Random chunks of
+    removals, generated embeddings and manual diffs go through write_vector_points twice -- over plain
+    in-memory writers and over the GPU writers -- and after every build the sealed stores must hold
+    exactly what the plain writers built, vector for vector."""
+    from search_engine_amd import _host
+    rng = np.random.default_rng(4000 + seed)
+    category, dim, n_docs = 20 + seed, 4, 150
+    pool = [[float(x) for x in rng.integers(-3, 4, dim)] for _ in range(40)]  # few distinct vectors: deletions by value hit
+    pool = [v for v in pool if any(v)]
+    plain = {}
+
+    def plain_writers(k):
+        return plain.setdefault(k, _ListWriter())
+
+    gpu = _host.GpuWriters(gpu_ctx.handle.value, category, dim, 64)  # 64 slots: growth on the way
+    try:
+        for chunk in range(30):
+            points = {"remove_vectors": [], "embeddings": [], "manual_vectors": []}
+            kind = rng.choice(["manual", "manual", "embeddings", "remove", "mixed"])
+            if kind in ("remove", "mixed"):
+                points["remove_vectors"] = sorted({int(d) for d in rng.integers(0, n_docs, int(rng.integers(1, 12)))})
+            if kind in ("embeddings", "mixed"):
+                for d in sorted({int(d) for d in rng.integers(0, n_docs, int(rng.integers(1, 25)))}):
+                    vecs = [pool[int(i)] for i in rng.integers(0, len(pool), int(rng.integers(1, 4)))]
+                    points["embeddings"].append((d, vecs))
+            if kind in ("manual", "mixed"):
+                for _ in range(int(rng.integers(1, 30))):
+                    d = int(rng.integers(0, n_docs))
+                    have = [w.items[d] for _, w in sorted(plain.items()) if d in w.items]
+                    deletion = addition = None
+                    r = rng.random()
+                    if have and r < 0.5:  # delete one of its vectors (sometimes one it does not have)
+                        deletion = have[int(rng.integers(0, len(have)))] if rng.random() < 0.8 else pool[0]
+                    if r > 0.3 and len(have) < 6:
+                        addition = pool[int(rng.integers(0, len(pool)))]
+                    if deletion is None and addition is None:
+                        addition = pool[int(rng.integers(0, len(pool)))]
+                    points["manual_vectors"].append((d, deletion, addition))
+            # generated embeddings replace a document's vectors: the reference deletes them first in the same chunk
+            if points["embeddings"]:
+                points["remove_vectors"] = sorted(set(points["remove_vectors"]) | {d for d, _ in points["embeddings"]})
+            _host.write_vector_points(plain_writers, points)
+            _host.write_vector_points(gpu, points)
+            n_plain = _host.build_vector_stores(plain_writers)
+            n_gpu = _host.build_vector_stores(gpu)
+            assert n_plain == n_gpu, (chunk, kind)
+            # the one deviation from the reference's build loop (index_documents/mod.rs:559-561 leaves an
+            # emptied writer unbuilt): a store must not go on answering with removed items, so the
+            # emptied stores behind the last built one are sealed empty
+            for k, w in plain.items():
+                if k >= n_plain and not w.items:
+                    w.built = {}
+            for k, w in sorted(plain.items()):
+                if not w.built and k >= n_gpu:
+                    continue  # never built: no store opens
+                try:
+                    store = gpu_ctx.open_store((category << 8) | k)
+                except Exception:  # noqa: BLE001
+                    assert not w.built, (chunk, k)
+                    continue
+                assert len(store) == len(w.built), (chunk, kind, k)
+                ids, _ = store.search(np.ones(dim, np.float32), 1024)
+                assert sorted(ids.tolist()) == sorted(w.built), (chunk, kind, k)
+                if k < n_gpu:  # built in this run: the writer's view is the sealed one
+                    for d, v in w.built.items():
+                        assert store.item_vector(d).tolist() == v, (chunk, kind, k, d)
+    finally:
+        del gpu
+        _destroy_stores(gpu_ctx, category, n=12)
