@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 3's benchmark lines on the final library (no profiler): written to gpurun_out/r03m_*.
+# The benchmark lines on the final library (no profiler): written to gpurun_out/r03m_*.
 set -e
 cd "$(dirname "$0")/.."
 O=gpurun_out

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 3: vs_search_batch_device on 10 M x 768 bf16, 256 queries: per-launch timing and the HBM bytes of one call.
+# vs_search_batch_device on 10 M x 768 bf16, 256 queries: per-launch timing and the HBM bytes of one call.
 set -e
 cd "$(dirname "$0")/.."
 tools/profile_pass.sh r03_batch_stats stats -- python3 $PWD/tools/batch_probe.py --docs 10000000 --pass-percents 100,10,1 --reps 6

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 3: the single-query scans with one launch per step of 16 queries. Kernel timing and FETCH_SIZE
+# the single-query scans with one launch per step of 16 queries. Kernel timing and FETCH_SIZE
 # passes (never in one run) of bench.py for the f32 headline (100 / 10 / 1 %), BASELINE config 2 (1 M rows),
 # the bf16 headline and the Hamming scan.
 set -e
