@@ -82,3 +82,20 @@ def test_mixed_entry_points_from_eight_threads(gpu_ctx):
     finally:
         for st in stores:
             st.destroy()
+
+
+def test_searching_threads_beside_an_indexing_thread_through_the_host_mirror():
+    """search_engine_amd/stress_mirror (C++, built with the library): six threads in
+    execute_vector_search under ONE shared universe object while an indexing thread adds documents
+    with ever larger docids through write_vector_points and the build loop -- the stores grow and
+    are sealed under the searchers, and the universe's device copy is replaced while others still
+    search with it. Every result must be well-formed (no duplicate, nothing outside the universe,
+    nothing that was not written yet), nobody may throw, and after the last build the planted
+    document is the first hit."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "search_engine_amd", "stress_mirror")
+    if not os.path.exists(exe):
+        pytest.skip("search_engine_amd/stress_mirror is not built (make -C search_engine_amd/csrc)")
+    out = subprocess.run([exe, "6", "40"], capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), (out.stdout, out.stderr[-2000:])
