@@ -517,18 +517,23 @@ def main():
 
 
 def csrc_sha256():
-    """Hash of the sources libvs_amd.so is built from (search_engine_amd/csrc/vs_* and its Makefile;
-    the host mirror beside them is compiled into its own users, not into the library): names a
-    build for the recorded-traffic check. (The tree travels to the GPU box without its .git, so a
-    git tree hash cannot be asked for there; this is the same information from the files themselves.)"""
+    """Hash of what libvs_amd.so is built from -- search_engine_amd/csrc/vs_* and the Makefile's
+    compiler, architecture, flags and source lists (the host mirror and the programs beside them are
+    compiled into their own users, not into the library): names a build for the recorded-traffic
+    check. (The tree travels to the GPU box without its .git, so a git tree hash cannot be asked for
+    there; this is the same information from the files themselves.)"""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "search_engine_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if (name.startswith("vs_") and name.endswith((".hip", ".h", ".cpp"))) or name == "Makefile":
+        if name.startswith("vs_") and name.endswith((".hip", ".h", ".cpp")):
             h.update(name.encode())
             with open(os.path.join(d, name), "rb") as f:
                 h.update(f.read())
+    with open(os.path.join(d, "Makefile")) as f:
+        for line in f:
+            if line.split(" ", 1)[0] in ("HIPCC", "ARCH", "CXXFLAGS", "SRCS_HIP", "SRCS_CPP"):
+                h.update(line.encode())
     return h.hexdigest()
 
 

@@ -78,3 +78,30 @@ def test_world_size_mismatch_is_refused():
     out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-launch"], env=env, capture_output=True,
                          text=True, timeout=120)
     assert out.returncode != 0 and "WORLD_SIZE" in out.stderr
+
+
+def test_recorded_traffic_is_tied_to_the_library_sources():
+    """profiles/scan_traffic*.json carry a hash of the sources libvs_amd.so is built from; bench.py
+    reports a number recorded on other sources as stale. The committed files must match the tree
+    they are committed with, and the hash must not move with files that are not in the library."""
+    import glob
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    now = bench.csrc_sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "scan_traffic*.json")))
+    assert files
+    for f in files:
+        with open(f) as fh:
+            assert json.load(fh).get("csrc_sha256") == now, f"{os.path.basename(f)} was recorded on other kernel sources"
+    mirror = os.path.join(ROOT, "search_engine_amd", "csrc", "host_engine.cpp")
+    with open(mirror, "rb") as fh:
+        before = fh.read()
+    try:
+        with open(mirror, "ab") as fh:
+            fh.write(b"\n// (test)\n")
+        assert bench.csrc_sha256() == now
+    finally:
+        with open(mirror, "wb") as fh:
+            fh.write(before)
