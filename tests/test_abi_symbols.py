@@ -60,3 +60,36 @@ def test_header_is_plain_c(tmp_path):
                    "  return (s == 0) + (c == 0) + (m == 0) + VS_MAX_K; }\n")
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only",
                     "-I", os.path.join(ROOT, "include"), str(src)], check=True)
+
+
+def test_the_rust_binding_in_the_integration_notes_matches_the_header():
+    """INTEGRATION.md shows the `extern "C"` block a maintainer would add on the Rust side. Every
+    function it declares must exist in include/vs_abi.h with the same number of parameters and the
+    same widths in the same order (u16/u32/u64/i32/f32 scalars, pointers, usize = size_t)."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    header = open(os.path.join(root, "include", "vs_abi.h")).read()
+    header = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)
+
+    def c_kind(p):
+        p = p.strip()
+        if "*" in p:
+            return "ptr"
+        t = p.rsplit(" ", 1)[0].replace("const ", "").strip()
+        return {"uint16_t": "u16", "uint32_t": "u32", "uint64_t": "u64", "int32_t": "i32", "float": "f32",
+                "size_t": "usize", "uint8_t": "u8"}[t]
+
+    def rust_kind(p):
+        t = p.split(":", 1)[1].strip()
+        return "ptr" if t.startswith("*") else t
+
+    rust = re.findall(r"pub fn (vs_\w+)\((.*?)\)\s*->\s*i32;", text, flags=re.S)
+    assert len(rust) >= 15
+    for name, params in rust:
+        m = re.search(r"int32_t\s+" + name + r"\s*\((.*?)\)\s*;", header, flags=re.S)
+        assert m, f"{name} is not declared in include/vs_abi.h"
+        c_params = [c_kind(p) for p in m.group(1).split(",")]
+        r_params = [rust_kind(p) for p in re.sub(r"\s+", " ", params).split(",") if p.strip()]
+        assert c_params == r_params, (name, c_params, r_params)
