@@ -93,3 +93,29 @@ def test_the_rust_binding_in_the_integration_notes_matches_the_header():
         c_params = [c_kind(p) for p in m.group(1).split(",")]
         r_params = [rust_kind(p) for p in re.sub(r"\s+", " ", params).split(",") if p.strip()]
         assert c_params == r_params, (name, c_params, r_params)
+
+
+def test_the_ctypes_signatures_match_the_header():
+    """abi.py's argtypes are what every GPU test calls through: same parameter count as the header
+    and the same scalar widths at the same positions (a pointer is a pointer)."""
+    import re
+    from search_engine_amd import abi
+    header = re.sub(r"/\*.*?\*/", " ", open(os.path.join(ROOT, "include", "vs_abi.h")).read(), flags=re.S)
+    scalars = {"uint16_t": ctypes.c_uint16, "uint32_t": ctypes.c_uint32, "uint64_t": ctypes.c_uint64,
+               "int32_t": ctypes.c_int32, "float": ctypes.c_float, "size_t": ctypes.c_size_t, "uint8_t": ctypes.c_uint8}
+    for name, argtypes in abi.SIGNATURES.items():
+        m = re.search(r"int32_t\s+" + name + r"\s*\((.*?)\)\s*;", header, flags=re.S)
+        assert m, name
+        params = [p.strip() for p in m.group(1).split(",")]
+        if params == ["void"]:
+            params = []
+        assert len(params) == len(argtypes), (name, params, argtypes)
+        for p, t in zip(params, argtypes):
+            if "*" in p:
+                is_pointer = t in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(t, "contents") or \
+                    issubclass(t, (ctypes._Pointer, ctypes.Array)) or t is ctypes.c_void_p
+                assert is_pointer, (name, p, t)
+            else:
+                want = scalars[p.rsplit(" ", 1)[0].replace("const ", "").strip()]
+                assert ctypes.sizeof(t) == ctypes.sizeof(want) and t is not ctypes.c_void_p, (name, p, t)
+                assert (t in (ctypes.c_float,)) == (want is ctypes.c_float), (name, p, t)
