@@ -88,3 +88,37 @@ def test_all_stores_in_one_call_equal_the_loop_over_stores(gpu_ctx, n_stores, dt
     finally:
         for st in stores:
             st.destroy()
+
+
+def test_stores_of_a_shard_that_starts_at_a_docid_base(gpu_ctx):
+    """One GPU's share of a sharded index: every store of the embedder starts at the shard's first
+    docid, filters name global docids (dense words from docid 0, a RoaringBitmap, a mask made for the
+    first store), and the shard's stores differ in capacity. One call = the loop over vs_search."""
+    from search_engine_amd import abi
+    category, base, n, dim, k = 23, 64 * 100, 5000, 64, 10
+    rng = np.random.default_rng(9)
+    stores = []
+    try:
+        for j in range(3):
+            have = (base + np.sort(rng.choice(n, n // (j + 1), replace=False))).astype(np.uint32)
+            cap = n if j != 1 else int(have.max()) - base + 1
+            st = gpu_ctx.create_store((category << 8) | j, dim, cap, docid_base=base)
+            stores.append(st)
+            st.upload(have, synthetic_vectors(have.size, dim, 300 + j))
+            st.seal()
+        q = synthetic_vectors(1, dim, 310)[0]
+        mask = facet_mask(base + n, 40)  # words over global docids, from docid 0
+        want = _loop(stores, q, k, lambda st, q, kk: st.search(q, kk, mask))
+        assert all(base <= i < base + n for i in want[0]) and len(want[0]) == 3 * k
+        handle = stores[0].create_mask(mask)
+        for kwargs in ({"mask": mask}, {"roaring_bytes": abi.mask_to_roaring(mask)}, {"mask_handle": handle}):
+            ids, dist, src, ns = gpu_ctx.search_stores(category << 8, q, k, **kwargs)
+            assert ns == 3
+            assert ids.tolist() == want[0] and dist.tobytes() == want[1].tobytes() and src.tolist() == want[2], kwargs
+        want = _loop(stores, q, k, lambda st, q, kk: st.search(q, kk))
+        ids, dist, src, _ = gpu_ctx.search_stores(category << 8, q, k)
+        assert ids.tolist() == want[0] and dist.tobytes() == want[1].tobytes() and src.tolist() == want[2]
+        stores[0].destroy_mask(handle)
+    finally:
+        for st in stores:
+            st.destroy()
